@@ -1,0 +1,201 @@
+/*
+ * rtc_hip.h — C-ABI of the MI355X (gfx950) render path for the Zig ray tracer
+ * stevschmid/raytracer-challenge.
+ *
+ * The library replaces the body of Camera.render (camera.zig:74-89) and everything
+ * it calls: calc.worldColorAt (calc.zig:641-652), calc.intersectWorld (calc.zig:200-214),
+ * calc.prepareComputations (calc.zig:247-306), calc.shadeHit (calc.zig:448-470),
+ * calc.isShadowed (calc.zig:777-790), calc.lighting (calc.zig:26-73),
+ * calc.reflectedColor (calc.zig:945-959), calc.refractedColor (calc.zig:828-853),
+ * calc.schlick (calc.zig:1004-1026), Shape.intersect / Shape.normalAt (shape.zig:84-107)
+ * and Pattern.patternAt (pattern.zig:77-91).
+ *
+ * Everything here is plain C: fixed-width integers, doubles, raw pointers.  Every
+ * function returns an int status (RTC_OK == 0); the message of the last failure on
+ * the calling thread is available from rtc_last_error().  No exceptions cross the ABI.
+ *
+ * All arithmetic on the path is IEEE-754 binary64 with no fused multiply-add and the
+ * reference's evaluation order, so the colours written are value-identical to what the
+ * Zig code computes from the same descriptors.
+ */
+#ifndef RTC_HIP_H
+#define RTC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------- */
+#define RTC_OK 0
+#define RTC_ERR_INVALID_ARGUMENT 1   /* null pointer, zero size, bad enum value          */
+#define RTC_ERR_SINGULAR_TRANSFORM 2 /* |det| <= f64 epsilon: matrix.zig:288 would panic */
+#define RTC_ERR_NOT_AFFINE 3         /* inverse's last row is not (0,0,0,1)              */
+#define RTC_ERR_DUPLICATE_SHAPE 4    /* two value-identical shapes (calc.zig:274,280)    */
+#define RTC_ERR_OUT_OF_MEMORY 5      /* maps to Zig's error.OutOfMemory                  */
+#define RTC_ERR_DEVICE 6             /* a HIP call failed; see rtc_last_error()          */
+#define RTC_ERR_TOO_LARGE 7          /* size beyond what an entry point supports         */
+
+/* ---- enums (declaration order of the reference's unions) ----------------- */
+/* Shape.geo, shape.zig:76-79 */
+#define RTC_GEO_SPHERE 0
+#define RTC_GEO_PLANE 1
+/* Pattern.pattern, pattern.zig:67-73 */
+#define RTC_PATTERN_POINT 0
+#define RTC_PATTERN_STRIPE 1
+#define RTC_PATTERN_GRADIENT 2
+#define RTC_PATTERN_RING 3
+#define RTC_PATTERN_CHECKERS 4
+
+/* ---- plain-old-data descriptors ------------------------------------------ */
+/* Pattern (pattern.zig:64-75).  a/b are unused for RTC_PATTERN_POINT.
+ * transform is Mat4.mat row-major (matrix.zig:103). */
+typedef struct RtcPatternDesc {
+    int32_t kind;
+    int32_t _pad0;
+    double a[3];
+    double b[3];
+    double transform[16];
+} RtcPatternDesc;
+
+/* Material (material.zig:6-18).  has_pattern == 0 is Zig's `pattern: ?Pattern = null`. */
+typedef struct RtcMaterialDesc {
+    double color[3];
+    double ambient;
+    double diffuse;
+    double specular;
+    double shininess;
+    double reflective;
+    double transparency;
+    double refractive_index;
+    int32_t has_pattern;
+    int32_t _pad0;
+    RtcPatternDesc pattern;
+} RtcMaterialDesc;
+
+/* Shape (shape.zig:73-82). */
+typedef struct RtcShapeDesc {
+    int32_t geo;
+    int32_t _pad0;
+    double transform[16];
+    RtcMaterialDesc material;
+} RtcShapeDesc;
+
+/* PointLight (light.zig:9-14).  position is a Vec4 (x,y,z,w) and must have w == 1. */
+typedef struct RtcLightDesc {
+    double position[4];
+    double intensity[3];
+} RtcLightDesc;
+
+/* Camera (camera.zig:20-27), as produced by the unchanged Camera.init (camera.zig:29-46);
+ * the library never evaluates tan(). */
+typedef struct RtcCameraDesc {
+    uint64_t hsize;
+    uint64_t vsize;
+    double field_of_view;
+    double half_width;
+    double half_height;
+    double pixel_size;
+    double transform[16];
+} RtcCameraDesc;
+
+/* Work counters of one call.  radiance_rays counts calc.worldColorAt invocations
+ * (primary + reflected + refracted), shadow_rays counts calc.isShadowed invocations;
+ * each is one full sweep over every shape.  sphere_hits / plane_hits count the
+ * (ray, shape) pairs whose local intersect produced t values (shape.zig:35,62).
+ * shaded_hits counts calc.shadeHit invocations.  kernel_ms is the device time of the
+ * render kernel measured with HIP events on the stream it ran on. */
+typedef struct RtcStats {
+    uint64_t radiance_rays;
+    uint64_t shadow_rays;
+    uint64_t sphere_tests;
+    uint64_t plane_tests;
+    uint64_t sphere_hits;
+    uint64_t plane_hits;
+    uint64_t shaded_hits;
+    uint64_t pixels;
+    double kernel_ms;
+} RtcStats;
+
+/* Opaque handle of an uploaded world (World, world.zig:15-28). */
+typedef struct RtcScene RtcScene;
+
+/* ---- entry points -------------------------------------------------------- */
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* rtc_last_error(void);
+
+/* Number of visible GPUs / select the GPU used by later calls of this thread. */
+int rtc_device_count(int32_t* count);
+int rtc_set_device(int32_t device);
+
+/* Flatten a world (world.zig:15-28: objects in list order, one light) into device
+ * buffers on the current GPU.  For every shape and pattern the inverse transform is
+ * computed once on the host with the reference's cofactor algorithm (matrix.zig:286-300),
+ * which yields the same bits as the reference's per-call recomputation.  Rejects
+ * singular and non-affine transforms and value-identical duplicate shapes.
+ * n_shapes may be 0 (every ray misses, calc.zig:649-651). */
+int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLightDesc* light,
+                     RtcScene** out_scene);
+int rtc_scene_destroy(RtcScene* scene);
+
+/* Camera.render (camera.zig:74-89): fill out_rgb (host memory, hsize*vsize*3 doubles,
+ * pixel (x,y) at index (y*hsize + x)*3 as canvas.zig:25, channels red,green,blue as
+ * color.zig:7-9) with calc.worldColorAt(world, rayForPixel(x,y), depth).  The
+ * reference hard-codes depth 5 (camera.zig:83).  stats may be NULL. */
+int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, double* out_rgb,
+               RtcStats* stats);
+
+/* Same, with the framebuffer left in device memory and an optional tile partition for
+ * multi-GPU rendering.  The image is cut into tiles of RTC_TILE_W x RTC_TILE_H pixels,
+ * numbered row-major; this call renders tiles t with t % tile_ranks == tile_rank.
+ * With tile_ranks == 1, d_out_rgb is the full row-major canvas.  Otherwise d_out_rgb is
+ * the rank's dense tile buffer: local tile k (global tile k*tile_ranks + tile_rank)
+ * occupies doubles [k*RTC_TILE_W*RTC_TILE_H*3, ...) row-major inside the tile; pixels
+ * of edge tiles that fall outside the canvas are left untouched.
+ * hip_stream is a hipStream_t (NULL = default stream).  The launch is asynchronous
+ * unless stats != NULL, in which case the call synchronises the stream and fills stats. */
+#define RTC_TILE_W 64
+#define RTC_TILE_H 8
+int rtc_render_device(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth,
+                      uint32_t tile_rank, uint32_t tile_ranks, void* d_out_rgb, void* hip_stream,
+                      RtcStats* stats);
+
+/* Number of doubles rtc_render_device writes into for (camera, tile_rank, tile_ranks). */
+int rtc_tile_buffer_doubles(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks,
+                            uint64_t* out_doubles);
+
+/* Scatter the gathered per-rank tile buffers (rank r's buffer at d_gathered +
+ * r*per_rank_doubles) back into the row-major canvas d_out_rgb (device memory). */
+int rtc_deinterleave_device(const RtcCameraDesc* camera, uint32_t tile_ranks,
+                            uint64_t per_rank_doubles, const void* d_gathered, void* d_out_rgb,
+                            void* hip_stream);
+
+/* calc.worldColorAt (calc.zig:641-652) for caller-supplied rays: rays holds n_rays
+ * records of 6 doubles (origin x,y,z then direction x,y,z; origin.w = 1 and
+ * direction.w = 0 are implied), out_rgb receives n_rays*3 doubles.  Host pointers. */
+int rtc_color_at(RtcScene* scene, const double* rays, uint64_t n_rays, int32_t depth,
+                 double* out_rgb, RtcStats* stats);
+
+/* byteColorValue (ppm.zig:6-9) on the device: out[i] = (uint8_t)clamp(rgb[i]*256, 0, 255)
+ * for n_values doubles.  Device pointers. */
+int rtc_quantize_u8_device(const void* d_rgb, uint64_t n_values, void* d_out_u8, void* hip_stream);
+
+/* ---- diagnostics (used by the parity tests) ------------------------------ */
+
+/* Mat4.inverse (matrix.zig:286-300) and Mat4.determinant (matrix.zig:272-280) exactly as
+ * rtc_scene_create evaluates them on the host; m and out_inv are 16 doubles row-major.
+ * Returns RTC_ERR_SINGULAR_TRANSFORM where the reference's assert (matrix.zig:288) fires. */
+int rtc_mat4_inverse(const double* m, double* out_inv, double* out_det);
+
+/* Element-wise a[i]/b[i], sqrt(a[i]) and std.math.pow(a[i], b[i]) (as used at
+ * calc.zig:67,1024,1025) computed ON THE DEVICE with the code paths the render kernel
+ * uses, for bit-level comparison with the host's IEEE results.  Host pointers. */
+int rtc_arith_probe(const double* a, const double* b, uint64_t n, double* out_div, double* out_sqrt,
+                    double* out_pow);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTC_HIP_H */

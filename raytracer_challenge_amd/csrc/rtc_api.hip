@@ -1,0 +1,571 @@
+// Host side of librtc_hip.so: the C-ABI declared in include/rtc_hip.h.
+//
+// Scene upload flattens the reference's World (world.zig:15-28) into device tables and
+// precomputes, once per shape / pattern / camera, the inverse the reference recomputes on
+// every call (shape.zig:85,100; pattern.zig:78-79; camera.zig:62) with the reference's own
+// cofactor algorithm, so the bits are the same.
+#include "rtc_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int fail_hip(const char* what, hipError_t e) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipErrorOutOfMemory ? RTC_ERR_OUT_OF_MEMORY : RTC_ERR_DEVICE;
+}
+
+#define HIP_TRY(expr)                                 \
+    do {                                              \
+        hipError_t _e = (expr);                       \
+        if (_e != hipSuccess) return fail_hip(#expr, _e); \
+    } while (0)
+
+constexpr double kF64Eps = 2.220446049250313080847263336181640625e-16;
+
+// ---- Mat4.inverse, matrix.zig:238-300 -------------------------------------------------
+// Cofactor expansion exactly as the reference evaluates it: Mat2 determinant a*d - b*c
+// (matrix.zig:23-26); Mat3 and Mat4 determinants accumulate `det += m[0][col] * cofactor`
+// from zero over the first row (matrix.zig:88-96, 272-280); cofactor = +-minor by parity of
+// row+col; inverse[row][col] = cofactor(col,row) / det.  Index lists replace the
+// reference's sub-matrix copies; the arithmetic and its order are unchanged.
+double det3_of(const double m[16], const int rows[3], const int cols[3]) {
+    auto at = [&](int r, int c) { return m[rows[r] * 4 + cols[c]]; };
+    const double minor0 = at(1, 1) * at(2, 2) - at(1, 2) * at(2, 1);
+    const double minor1 = at(1, 0) * at(2, 2) - at(1, 2) * at(2, 0);
+    const double minor2 = at(1, 0) * at(2, 1) - at(1, 1) * at(2, 0);
+    double det = 0;
+    det += at(0, 0) * minor0;
+    det += at(0, 1) * -minor1;
+    det += at(0, 2) * minor2;
+    return det;
+}
+
+double cofactor4(const double m[16], int row, int col) {
+    int rows[3], cols[3];
+    for (int i = 0, k = 0; i < 4; ++i)
+        if (i != row) rows[k++] = i;
+    for (int i = 0, k = 0; i < 4; ++i)
+        if (i != col) cols[k++] = i;
+    const double minor = det3_of(m, rows, cols);
+    return ((row + col) % 2 != 0) ? -minor : minor;
+}
+
+double det4(const double m[16]) {
+    double det = 0;
+    for (int col = 0; col < 4; ++col) det += m[col] * cofactor4(m, 0, col);
+    return det;
+}
+
+// Returns RTC_OK and the full 4x4 inverse, or the reason the transform is unusable.
+int invert_affine(const double m[16], double inv[16], const char* what, uint64_t index) {
+    const double det = det4(m);
+    // matrix.zig:288 asserts !epsilonEq(det, 0): |det - 0| <= f64 epsilon is a panic there
+    if (!(std::fabs(det - 0.0) > kF64Eps)) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "%s %llu: transform is not invertible (det = %g)", what,
+                      (unsigned long long)index, det);
+        return fail(RTC_ERR_SINGULAR_TRANSFORM, buf);
+    }
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) inv[row * 4 + col] = cofactor4(m, col, row) / det;
+    // The kernels carry points as (x,y,z,1) and directions as (x,y,z,0); that is exact only
+    // when the inverse maps w to w, i.e. its last row is (0,0,0,1).
+    if (!(inv[12] == 0.0 && inv[13] == 0.0 && inv[14] == 0.0 && inv[15] == 1.0)) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "%s %llu: transform is not affine (inverse last row %g %g %g %g)", what,
+                      (unsigned long long)index, inv[12], inv[13], inv[14], inv[15]);
+        return fail(RTC_ERR_NOT_AFFINE, buf);
+    }
+    return RTC_OK;
+}
+
+// ---- value equality of two shapes, std.meta.eql (calc.zig:274,280) ---------------------
+// Field-wise ==; floats compare with == (so -0 == 0, NaN != NaN); the optional pattern by
+// presence, then tag, then payload (the `point` tag has no colours).
+bool eq_doubles(const double* a, const double* b, int n) {
+    for (int i = 0; i < n; ++i)
+        if (!(a[i] == b[i])) return false;
+    return true;
+}
+bool shapes_equal(const RtcShapeDesc& a, const RtcShapeDesc& b) {
+    if (a.geo != b.geo || !eq_doubles(a.transform, b.transform, 16)) return false;
+    const RtcMaterialDesc &m = a.material, &n = b.material;
+    if (!eq_doubles(m.color, n.color, 3) || !(m.ambient == n.ambient) || !(m.diffuse == n.diffuse) ||
+        !(m.specular == n.specular) || !(m.shininess == n.shininess) || !(m.reflective == n.reflective) ||
+        !(m.transparency == n.transparency) || !(m.refractive_index == n.refractive_index))
+        return false;
+    if ((m.has_pattern != 0) != (n.has_pattern != 0)) return false;
+    if (!m.has_pattern) return true;
+    if (m.pattern.kind != n.pattern.kind) return false;
+    if (m.pattern.kind != RTC_PATTERN_POINT &&
+        !(eq_doubles(m.pattern.a, n.pattern.a, 3) && eq_doubles(m.pattern.b, n.pattern.b, 3)))
+        return false;
+    return eq_doubles(m.pattern.transform, n.pattern.transform, 16);
+}
+// Hash consistent with shapes_equal (zeros canonicalised; a NaN anywhere makes the shape
+// unequal to everything, itself included, so such shapes are never reported).
+struct ShapeHasher {
+    uint64_t h = 1469598103934665603ull;
+    bool has_nan = false;
+    void word(uint64_t v) {
+        for (int i = 0; i < 8; ++i) {
+            h ^= (v >> (8 * i)) & 0xff;
+            h *= 1099511628211ull;
+        }
+    }
+    void f64(double d) {
+        if (d != d) has_nan = true;
+        if (d == 0.0) d = 0.0;
+        uint64_t u;
+        std::memcpy(&u, &d, 8);
+        word(u);
+    }
+    void f64s(const double* p, int n) {
+        for (int i = 0; i < n; ++i) f64(p[i]);
+    }
+};
+uint64_t hash_shape(const RtcShapeDesc& s, bool* has_nan) {
+    ShapeHasher H;
+    H.word((uint64_t)s.geo);
+    H.f64s(s.transform, 16);
+    const RtcMaterialDesc& m = s.material;
+    H.f64s(m.color, 3);
+    H.f64(m.ambient);
+    H.f64(m.diffuse);
+    H.f64(m.specular);
+    H.f64(m.shininess);
+    H.f64(m.reflective);
+    H.f64(m.transparency);
+    H.f64(m.refractive_index);
+    H.word(m.has_pattern ? 1 : 0);
+    if (m.has_pattern) {
+        H.word((uint64_t)m.pattern.kind);
+        if (m.pattern.kind != RTC_PATTERN_POINT) {
+            H.f64s(m.pattern.a, 3);
+            H.f64s(m.pattern.b, 3);
+        }
+        H.f64s(m.pattern.transform, 16);
+    }
+    *has_nan = H.has_nan;
+    return H.h;
+}
+
+bool valid_stream_and_ptr(const void* p) { return p != nullptr; }
+
+}  // namespace
+
+// ---- the opaque scene ---------------------------------------------------------------------
+struct RtcScene {
+    int device = 0;
+    uint64_t n = 0;
+    uint64_t n_spheres = 0, n_planes = 0;
+    double* d_inv = nullptr;
+    int32_t* d_geo = nullptr;
+    rtc::DevShade* d_shade = nullptr;
+    uint32_t* d_counter = nullptr;  // work-queue head (4 B) followed by 5 x uint64 stats
+    uint64_t* d_stats = nullptr;
+    double light_pos[3] = {0, 0, 0};
+    double light_int[3] = {0, 0, 0};
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+namespace {
+
+void free_scene(RtcScene* s) {
+    if (!s) return;
+    if (s->d_inv) (void)hipFree(s->d_inv);
+    if (s->d_geo) (void)hipFree(s->d_geo);
+    if (s->d_shade) (void)hipFree(s->d_shade);
+    if (s->d_counter) (void)hipFree(s->d_counter);
+    if (s->ev_start) (void)hipEventDestroy(s->ev_start);
+    if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+    delete s;
+}
+
+rtc::DevWorld dev_world(const RtcScene* s) {
+    rtc::DevWorld w{};
+    w.inv = s->d_inv;
+    w.geo = s->d_geo;
+    w.shade = s->d_shade;
+    w.n = (int32_t)s->n;
+    for (int i = 0; i < 3; ++i) {
+        w.light_pos[i] = s->light_pos[i];
+        w.light_int[i] = s->light_int[i];
+    }
+    return w;
+}
+
+void tile_counts(uint64_t hsize, uint64_t vsize, uint32_t rank, uint32_t ranks, uint32_t* tiles_x,
+                 uint32_t* tiles_total, uint64_t* local_tiles) {
+    const uint64_t tx = (hsize + RTC_TILE_W - 1) / RTC_TILE_W, ty = (vsize + RTC_TILE_H - 1) / RTC_TILE_H;
+    const uint64_t total = tx * ty;
+    *tiles_x = (uint32_t)tx;
+    *tiles_total = (uint32_t)total;
+    *local_tiles = total > rank ? (total - rank + ranks - 1) / ranks : 0;
+}
+
+int check_camera(const RtcCameraDesc* c) {
+    if (!c) return fail(RTC_ERR_INVALID_ARGUMENT, "camera is NULL");
+    if (c->hsize == 0 || c->vsize == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "camera hsize/vsize must be non-zero");
+    const uint64_t tx = (c->hsize + RTC_TILE_W - 1) / RTC_TILE_W, ty = (c->vsize + RTC_TILE_H - 1) / RTC_TILE_H;
+    if (c->hsize > (1u << 20) || c->vsize > (1u << 20) || tx * ty * RTC_TILE_W * RTC_TILE_H > (1ull << 31))
+        return fail(RTC_ERR_TOO_LARGE, "canvas too large (at most 2^31 padded pixels)");
+    return RTC_OK;
+}
+
+// Fill stats from the device counters (after the stream has been synchronised).
+int read_stats(RtcScene* s, RtcStats* out, uint64_t pixels, float ms) {
+    uint64_t h[5];
+    HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    out->radiance_rays = h[0];
+    out->shadow_rays = h[1];
+    out->sphere_tests = (h[0] + h[1]) * s->n_spheres;
+    out->plane_tests = (h[0] + h[1]) * s->n_planes;
+    out->sphere_hits = h[2];
+    out->plane_hits = h[3];
+    out->shaded_hits = h[4];
+    out->pixels = pixels;
+    out->kernel_ms = ms;
+    return RTC_OK;
+}
+
+// Common launch path of rtc_render_device / rtc_render / rtc_color_at.
+int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, uint64_t pixels) {
+    if (job.depth > rtc::kMaxDepthLarge) {
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "depth %d exceeds the supported maximum %d", job.depth, rtc::kMaxDepthLarge);
+        return fail(RTC_ERR_TOO_LARGE, buf);
+    }
+    job.counter = s->d_counter;
+    job.stats = stats ? s->d_stats : nullptr;
+    if (job.total == 0) {
+        if (stats) {
+            std::memset(stats, 0, sizeof *stats);
+        }
+        return RTC_OK;
+    }
+    // zero the queue head and the stats words
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, 64, stream));
+    if (stats) HIP_TRY(hipEventRecord(s->ev_start, stream));
+    HIP_TRY(rtc::launch_render(dev_world(s), job, stats != nullptr, stream));
+    if (stats) {
+        HIP_TRY(hipEventRecord(s->ev_stop, stream));
+        HIP_TRY(hipEventSynchronize(s->ev_stop));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
+        return read_stats(s, stats, pixels, ms);
+    }
+    return RTC_OK;
+}
+
+int fill_camera_job(const RtcCameraDesc* camera, int32_t depth, uint32_t tile_rank, uint32_t tile_ranks,
+                    rtc::DevJob* job, uint64_t* local_pixels) {
+    if (int rc = check_camera(camera)) return rc;
+    if (tile_ranks == 0 || tile_rank >= tile_ranks)
+        return fail(RTC_ERR_INVALID_ARGUMENT, "tile_rank must be < tile_ranks and tile_ranks >= 1");
+    double cam_inv[16];
+    if (int rc = invert_affine(camera->transform, cam_inv, "camera", 0)) return rc;
+    std::memcpy(job->cam_inv, cam_inv, 12 * sizeof(double));
+    job->half_width = camera->half_width;
+    job->half_height = camera->half_height;
+    job->pixel_size = camera->pixel_size;
+    job->hsize = (uint32_t)camera->hsize;
+    job->vsize = (uint32_t)camera->vsize;
+    uint64_t local_tiles = 0;
+    tile_counts(camera->hsize, camera->vsize, tile_rank, tile_ranks, &job->tiles_x, &job->tiles_total, &local_tiles);
+    job->tile_rank = tile_rank;
+    job->tile_ranks = tile_ranks;
+    job->rays = nullptr;
+    job->total = (uint32_t)(local_tiles * RTC_TILE_W * RTC_TILE_H);
+    job->depth = depth;
+    *local_pixels = local_tiles * RTC_TILE_W * RTC_TILE_H;
+    return RTC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtc_last_error(void) { return g_last_error.c_str(); }
+
+int rtc_device_count(int32_t* count) {
+    if (!count) return fail(RTC_ERR_INVALID_ARGUMENT, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail_hip("hipGetDeviceCount", e);
+    }
+    *count = n;
+    return RTC_OK;
+}
+
+int rtc_set_device(int32_t device) {
+    HIP_TRY(hipSetDevice(device));
+    return RTC_OK;
+}
+
+int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLightDesc* light, RtcScene** out_scene) {
+    if (!out_scene) return fail(RTC_ERR_INVALID_ARGUMENT, "out_scene is NULL");
+    *out_scene = nullptr;
+    if (!light) return fail(RTC_ERR_INVALID_ARGUMENT, "light is NULL");
+    if (n_shapes > 0 && !shapes) return fail(RTC_ERR_INVALID_ARGUMENT, "shapes is NULL");
+    if (n_shapes > (1u << 24)) return fail(RTC_ERR_TOO_LARGE, "more than 2^24 shapes");
+    if (!(light->position[3] == 1.0))
+        return fail(RTC_ERR_INVALID_ARGUMENT, "light.position must be a point (w == 1)");
+
+    std::vector<double> inv(n_shapes * 12);
+    std::vector<int32_t> geo(n_shapes);
+    std::vector<rtc::DevShade> shade(n_shapes);
+    uint64_t n_spheres = 0, n_planes = 0;
+    std::unordered_map<uint64_t, std::vector<uint64_t>> buckets;
+    for (uint64_t i = 0; i < n_shapes; ++i) {
+        const RtcShapeDesc& s = shapes[i];
+        if (s.geo != RTC_GEO_SPHERE && s.geo != RTC_GEO_PLANE) {
+            char buf[96];
+            std::snprintf(buf, sizeof buf, "shape %llu: unknown geo %d", (unsigned long long)i, s.geo);
+            return fail(RTC_ERR_INVALID_ARGUMENT, buf);
+        }
+        (s.geo == RTC_GEO_SPHERE ? n_spheres : n_planes)++;
+        double full[16];
+        if (int rc = invert_affine(s.transform, full, "shape", i)) return rc;
+        std::memcpy(&inv[i * 12], full, 12 * sizeof(double));
+        geo[i] = s.geo;
+        rtc::DevShade& d = shade[i];
+        std::memset(&d, 0, sizeof d);
+        const RtcMaterialDesc& m = s.material;
+        std::memcpy(d.color, m.color, sizeof d.color);
+        d.ambient = m.ambient;
+        d.diffuse = m.diffuse;
+        d.specular = m.specular;
+        d.shininess = m.shininess;
+        d.reflective = m.reflective;
+        d.transparency = m.transparency;
+        d.refractive_index = m.refractive_index;
+        d.geo = s.geo;
+        d.pattern = -1;
+        if (m.has_pattern) {
+            const int k = m.pattern.kind;
+            if (k < RTC_PATTERN_POINT || k > RTC_PATTERN_CHECKERS) {
+                char buf[96];
+                std::snprintf(buf, sizeof buf, "shape %llu: unknown pattern kind %d", (unsigned long long)i, k);
+                return fail(RTC_ERR_INVALID_ARGUMENT, buf);
+            }
+            double pfull[16];
+            if (int rc = invert_affine(m.pattern.transform, pfull, "pattern of shape", i)) return rc;
+            std::memcpy(d.pat_inv, pfull, 12 * sizeof(double));
+            std::memcpy(d.pat_a, m.pattern.a, sizeof d.pat_a);
+            std::memcpy(d.pat_b, m.pattern.b, sizeof d.pat_b);
+            d.pattern = k;
+        }
+        // The reference identifies "the same object" by value (calc.zig:274,280); the kernels
+        // identify it by list index.  The two agree unless two shapes are value-identical.
+        bool has_nan = false;
+        const uint64_t h = hash_shape(s, &has_nan);
+        if (!has_nan) {
+            auto& bucket = buckets[h];
+            for (uint64_t j : bucket) {
+                if (shapes_equal(shapes[j], s)) {
+                    char buf[128];
+                    std::snprintf(buf, sizeof buf, "shapes %llu and %llu are value-identical", (unsigned long long)j,
+                                  (unsigned long long)i);
+                    return fail(RTC_ERR_DUPLICATE_SHAPE, buf);
+                }
+            }
+            bucket.push_back(i);
+        }
+    }
+
+    RtcScene* sc = new (std::nothrow) RtcScene();
+    if (!sc) return fail(RTC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    hipError_t e = hipGetDevice(&sc->device);
+    if (e != hipSuccess) {
+        free_scene(sc);
+        return fail_hip("hipGetDevice", e);
+    }
+    sc->n = n_shapes;
+    sc->n_spheres = n_spheres;
+    sc->n_planes = n_planes;
+    for (int i = 0; i < 3; ++i) {
+        sc->light_pos[i] = light->position[i];
+        sc->light_int[i] = light->intensity[i];
+    }
+    const size_t n_alloc = n_shapes ? n_shapes : 1;
+#define SCENE_TRY(expr)                 \
+    do {                                \
+        hipError_t _e = (expr);         \
+        if (_e != hipSuccess) {         \
+            free_scene(sc);             \
+            return fail_hip(#expr, _e); \
+        }                               \
+    } while (0)
+    SCENE_TRY(hipMalloc((void**)&sc->d_inv, n_alloc * 12 * sizeof(double)));
+    SCENE_TRY(hipMalloc((void**)&sc->d_geo, n_alloc * sizeof(int32_t)));
+    SCENE_TRY(hipMalloc((void**)&sc->d_shade, n_alloc * sizeof(rtc::DevShade)));
+    SCENE_TRY(hipMalloc((void**)&sc->d_counter, 64));
+    sc->d_stats = (uint64_t*)((char*)sc->d_counter + 8);
+    SCENE_TRY(hipEventCreate(&sc->ev_start));
+    SCENE_TRY(hipEventCreate(&sc->ev_stop));
+    if (n_shapes) {
+        SCENE_TRY(hipMemcpy(sc->d_inv, inv.data(), n_shapes * 12 * sizeof(double), hipMemcpyHostToDevice));
+        SCENE_TRY(hipMemcpy(sc->d_geo, geo.data(), n_shapes * sizeof(int32_t), hipMemcpyHostToDevice));
+        SCENE_TRY(hipMemcpy(sc->d_shade, shade.data(), n_shapes * sizeof(rtc::DevShade), hipMemcpyHostToDevice));
+    }
+#undef SCENE_TRY
+    *out_scene = sc;
+    return RTC_OK;
+}
+
+int rtc_scene_destroy(RtcScene* scene) {
+    free_scene(scene);
+    return RTC_OK;
+}
+
+int rtc_tile_buffer_doubles(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks,
+                            uint64_t* out_doubles) {
+    if (!out_doubles) return fail(RTC_ERR_INVALID_ARGUMENT, "out_doubles is NULL");
+    if (int rc = check_camera(camera)) return rc;
+    if (tile_ranks == 0 || tile_rank >= tile_ranks)
+        return fail(RTC_ERR_INVALID_ARGUMENT, "tile_rank must be < tile_ranks and tile_ranks >= 1");
+    if (tile_ranks == 1) {
+        *out_doubles = camera->hsize * camera->vsize * 3;
+        return RTC_OK;
+    }
+    uint32_t tx, tt;
+    uint64_t local;
+    tile_counts(camera->hsize, camera->vsize, tile_rank, tile_ranks, &tx, &tt, &local);
+    *out_doubles = local * RTC_TILE_W * RTC_TILE_H * 3;
+    return RTC_OK;
+}
+
+int rtc_render_device(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, uint32_t tile_rank,
+                      uint32_t tile_ranks, void* d_out_rgb, void* hip_stream, RtcStats* stats) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!valid_stream_and_ptr(d_out_rgb)) return fail(RTC_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
+    rtc::DevJob job{};
+    uint64_t local_pixels = 0;
+    if (int rc = fill_camera_job(camera, depth, tile_rank, tile_ranks, &job, &local_pixels)) return rc;
+    job.out = (double*)d_out_rgb;
+    const uint64_t pixels = tile_ranks == 1 ? camera->hsize * camera->vsize : local_pixels;
+    return run_job(scene, job, (hipStream_t)hip_stream, stats, pixels);
+}
+
+int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, double* out_rgb, RtcStats* stats) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!out_rgb) return fail(RTC_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
+    if (int rc = check_camera(camera)) return rc;
+    const size_t bytes = (size_t)camera->hsize * camera->vsize * 3 * sizeof(double);
+    double* d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_out, bytes));
+    int rc = rtc_render_device(scene, camera, depth, 0, 1, d_out, nullptr, stats);
+    if (rc == RTC_OK) {
+        hipError_t e = hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail_hip("hipMemcpy(out_rgb)", e);
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int rtc_color_at(RtcScene* scene, const double* rays, uint64_t n_rays, int32_t depth, double* out_rgb,
+                 RtcStats* stats) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (n_rays == 0) {
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return RTC_OK;
+    }
+    if (!rays || !out_rgb) return fail(RTC_ERR_INVALID_ARGUMENT, "rays/out_rgb is NULL");
+    if (n_rays > (1ull << 31)) return fail(RTC_ERR_TOO_LARGE, "more than 2^31 rays");
+    double *d_rays = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_rays, n_rays * 6 * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&d_out, n_rays * 3 * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipFree(d_rays);
+        return fail_hip("hipMalloc(d_out)", e);
+    }
+    int rc = RTC_OK;
+    e = hipMemcpy(d_rays, rays, n_rays * 6 * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail_hip("hipMemcpy(rays)", e);
+    if (rc == RTC_OK) {
+        rtc::DevJob job{};
+        job.rays = d_rays;
+        job.total = (uint32_t)n_rays;
+        job.depth = depth;
+        job.out = d_out;
+        job.tile_ranks = 1;
+        rc = run_job(scene, job, nullptr, stats, n_rays);
+    }
+    if (rc == RTC_OK) {
+        e = hipMemcpy(out_rgb, d_out, n_rays * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail_hip("hipMemcpy(out_rgb)", e);
+    }
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int rtc_deinterleave_device(const RtcCameraDesc* camera, uint32_t tile_ranks, uint64_t per_rank_doubles,
+                            const void* d_gathered, void* d_out_rgb, void* hip_stream) {
+    if (int rc = check_camera(camera)) return rc;
+    if (!d_gathered || !d_out_rgb) return fail(RTC_ERR_INVALID_ARGUMENT, "device pointer is NULL");
+    if (tile_ranks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "tile_ranks must be >= 1");
+    uint64_t need = 0;
+    if (int rc = rtc_tile_buffer_doubles(camera, 0, tile_ranks, &need)) return rc;
+    if (tile_ranks > 1 && per_rank_doubles < need)
+        return fail(RTC_ERR_INVALID_ARGUMENT, "per_rank_doubles smaller than rank 0's tile buffer");
+    HIP_TRY(rtc::launch_deinterleave((const double*)d_gathered, per_rank_doubles, tile_ranks, (uint32_t)camera->hsize,
+                                     (uint32_t)camera->vsize, (double*)d_out_rgb, (hipStream_t)hip_stream));
+    return RTC_OK;
+}
+
+int rtc_quantize_u8_device(const void* d_rgb, uint64_t n_values, void* d_out_u8, void* hip_stream) {
+    if (n_values == 0) return RTC_OK;
+    if (!d_rgb || !d_out_u8) return fail(RTC_ERR_INVALID_ARGUMENT, "device pointer is NULL");
+    HIP_TRY(rtc::launch_quantize((const double*)d_rgb, n_values, (uint8_t*)d_out_u8, (hipStream_t)hip_stream));
+    return RTC_OK;
+}
+
+int rtc_arith_probe(const double* a, const double* b, uint64_t n, double* out_div, double* out_sqrt,
+                    double* out_pow) {
+    if (n == 0) return RTC_OK;
+    if (!a || !b || !out_div || !out_sqrt || !out_pow) return fail(RTC_ERR_INVALID_ARGUMENT, "NULL pointer");
+    double* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, n * 5 * sizeof(double)));
+    int rc = RTC_OK;
+    hipError_t e = hipMemcpy(d, a, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rtc::launch_arith_probe(d, d + n, n, d + 2 * n, d + 3 * n, d + 4 * n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_div, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_sqrt, d + 3 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_pow, d + 4 * n, n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail_hip("rtc_arith_probe", e);
+    (void)hipFree(d);
+    return rc;
+}
+
+int rtc_mat4_inverse(const double* m, double* out_inv, double* out_det) {
+    if (!m || !out_inv) return fail(RTC_ERR_INVALID_ARGUMENT, "NULL pointer");
+    const double det = det4(m);
+    if (out_det) *out_det = det;
+    if (!(std::fabs(det - 0.0) > kF64Eps)) return fail(RTC_ERR_SINGULAR_TRANSFORM, "matrix is not invertible");
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) out_inv[row * 4 + col] = cofactor4(m, col, row) / det;
+    return RTC_OK;
+}
+
+}  // extern "C"

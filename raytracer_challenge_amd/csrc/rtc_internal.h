@@ -1,0 +1,71 @@
+// Internal declarations shared by the host side (rtc_api.hip) and the device side
+// (rtc_kernels.hip) of librtc_hip.so.  Nothing here is part of the C-ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtc_hip.h"
+
+namespace rtc {
+
+// Deepest recursion the kernels are instantiated for.  A node at `remaining == 0` never
+// spawns children (calc.zig:829,946), so `depth` frames suffice for depth `depth`.
+constexpr int kMaxDepthSmall = 5;   // the reference's hard-coded depth (camera.zig:83)
+constexpr int kMaxDepthLarge = 16;
+
+// Per-shape record read by one lane after it knows which shape it hit (a gather).
+// Everything a hit needs that the sweep table does not hold.
+struct DevShade {
+    double color[3];
+    double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+    double pat_a[3];
+    double pat_b[3];
+    double pat_inv[12];  // rows 0..2 of inverse(pattern.transform), row-major 3x4
+    int32_t geo;         // RTC_GEO_*
+    int32_t pattern;     // RTC_PATTERN_* or -1 when the material has no pattern
+};
+
+// Device-side view of an uploaded world.
+//
+// Layout in HBM (all allocated once per scene, read-only while rendering):
+//   inv   : n x 12 doubles — rows 0..2 of inverse(shape.transform), row-major 3x4.  The
+//           sweep reads it with wave-uniform addresses; 96 B per shape.
+//   geo   : n x int32      — RTC_GEO_* per shape, same order.
+//   shade : n x DevShade   — gathered per lane at a hit.
+struct DevWorld {
+    const double* inv;
+    const int32_t* geo;
+    const DevShade* shade;
+    int32_t n;
+    double light_pos[3];
+    double light_int[3];
+};
+
+// Work description of one launch.
+struct DevJob {
+    // camera (camera.zig:20-27) with the inverse of its transform precomputed on the host
+    double cam_inv[12];
+    double half_width, half_height, pixel_size;
+    uint32_t hsize, vsize;
+    // tile partition (see rtc_render_device in the public header)
+    uint32_t tiles_x, tiles_total, tile_rank, tile_ranks;
+    // explicit rays instead of camera rays (rtc_color_at): 6 doubles per ray, or nullptr
+    const double* rays;
+    uint32_t total;  // number of work items: local tile pixels (padding included) or rays
+    int32_t depth;
+    double* out;
+    uint32_t* counter;  // work-queue head, zeroed before the launch
+    uint64_t* stats;    // 5 counters (radiance, shadow, sphere hits, plane hits, shaded) or nullptr
+};
+
+// Launchers implemented in rtc_kernels.hip.  grid_blocks == 0 lets the launcher size the
+// grid from the device's CU count and the kernel's occupancy.
+hipError_t launch_render(const DevWorld& world, const DevJob& job, bool with_stats, hipStream_t stream);
+hipError_t launch_deinterleave(const double* gathered, uint64_t per_rank_doubles, uint32_t tile_ranks,
+                               uint32_t hsize, uint32_t vsize, double* out, hipStream_t stream);
+hipError_t launch_quantize(const double* rgb, uint64_t n, uint8_t* out, hipStream_t stream);
+hipError_t launch_arith_probe(const double* a, const double* b, uint64_t n, double* out_div, double* out_sqrt,
+                              double* out_pow, hipStream_t stream);
+
+}  // namespace rtc

@@ -1,0 +1,742 @@
+// Device side of librtc_hip.so: the per-pixel render path of the reference
+// (Camera.render -> calc.worldColorAt -> intersectWorld / prepareComputations / shadeHit /
+// isShadowed / lighting / reflectedColor / refractedColor / schlick) as one persistent
+// FP64 kernel for gfx950.
+//
+// Numerical contract: every floating-point expression below keeps the operation order of
+// the Zig source it cites, no multiply-add is ever fused (this file is compiled with
+// -ffp-contract=off and carries the pragma below), divisions and square roots are the
+// correctly rounded IEEE ones.  Vectors are carried as three components: on this path
+// points have w == 1 and directions w == 0 exactly, so the reference's fourth terms are
+// an exact "+ m3" or an added zero, and results are value-identical (only the sign of a
+// zero can differ).
+//
+// Execution model: one lane owns one pixel at a time.  The reference's recursion (a binary
+// tree of at most 2^(depth+1)-1 radiance rays) becomes an explicit per-lane frame stack
+// that is unwound in the reference's post-order, so the colour sums associate exactly as
+// in calc.zig:464-469.  Every loop iteration each live lane processes one tree node: a
+// radiance sweep over all shapes, then (on a hit) a shadow sweep and the shading.  The
+// sweep is brute force over the whole shape list, exactly the reference's list order, and
+// is identical work for every lane whatever ray it holds, so a wavefront never diverges
+// inside it; shape rows are read with wave-uniform addresses.  Lanes that finish a pixel
+// take the next one from a global queue (one atomic per wave, ballot + prefix count to
+// hand out indices), so lanes stay busy until the image is exhausted.
+#include "rtc_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace rtc {
+namespace {
+
+constexpr double kF64Eps = 2.220446049250313080847263336181640625e-16;  // std.math.epsilon(f64)
+constexpr double kSurfaceEps = 0.0001;                                   // calc.zig:262
+constexpr int kBlock = 256;
+
+struct V3 {
+    double x, y, z;
+};
+
+// vector.zig:99-104 with the w*w' term known to be zero
+__device__ __forceinline__ double dot3(const V3& a, const V3& b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// vector.zig:84-97 (w == 0): length, then one division per component
+__device__ __forceinline__ V3 normalize3(const V3& a) {
+    const double len = sqrt((a.x * a.x + a.y * a.y) + a.z * a.z);
+    return {a.x / len, a.y / len, a.z / len};
+}
+// matrix.zig:215-224 for a point (w == 1): ((m0*x + m1*y) + m2*z) + m3
+__device__ __forceinline__ V3 xform_point(const double* __restrict__ m, const V3& p) {
+    return {((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7],
+            ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]};
+}
+// matrix.zig:215-224 for a direction (w == 0)
+__device__ __forceinline__ V3 xform_dir(const double* __restrict__ m, const V3& d) {
+    return {(m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z,
+            (m[8] * d.x + m[9] * d.y) + m[10] * d.z};
+}
+
+// ---------------------------------------------------------------------------------------
+// std.math.pow of the Zig standard library (called at calc.zig:67,1024,1025).  That library
+// is outside the reference tree; its pow is a port of Go's math.Pow: special cases, frexp,
+// binary exponentiation over the integer part of y on the mantissa with renormalisation,
+// exp(yf*ln x) for a fractional part, scalbn.  Restated from that published algorithm.
+__device__ double zig_exp(double x) {  // musl/FreeBSD e_exp.c, which Zig's exp ports
+    const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                 P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    uint32_t hx = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32);
+    const int sign = (int)(hx >> 31);
+    hx &= 0x7fffffff;
+    if (hx >= 0x4086232b) {
+        if (x != x) return x;
+        if (x > 709.782712893383973096) return x * 0x1p1023;
+        if (x < -708.39641853226410622 && x < -745.13321910194110842) return 0;
+    }
+    double hi, lo;
+    int k;
+    if (hx > 0x3fd62e42) {
+        if (hx >= 0x3ff0a2b2)
+            k = (int)(invln2 * x + (sign ? -0.5 : 0.5));
+        else
+            k = 1 - sign - sign;
+        hi = x - k * ln2hi;
+        lo = k * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x3e300000) {
+        k = 0;
+        hi = x;
+        lo = 0;
+    } else {
+        return 1 + x;
+    }
+    const double xx = x * x;
+    const double c = x - xx * (P1 + xx * (P2 + xx * (P3 + xx * (P4 + xx * P5))));
+    const double y = 1 + (x * c / (2 - c) - lo + hi);
+    if (k == 0) return y;
+    return ldexp(y, k);
+}
+
+__device__ double zig_ln(double x) {  // musl/FreeBSD e_log.c, which Zig's ln ports
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    unsigned long long ix = (unsigned long long)__double_as_longlong(x);
+    uint32_t hx = (uint32_t)(ix >> 32);
+    int k = 0;
+    if (hx < 0x00100000 || (hx >> 31)) {
+        if ((ix << 1) == 0) return -1 / (x * x);
+        if (hx >> 31) return (x - x) / 0.0;
+        k -= 54;
+        x *= 0x1p54;
+        ix = (unsigned long long)__double_as_longlong(x);
+        hx = (uint32_t)(ix >> 32);
+    } else if (hx >= 0x7ff00000) {
+        return x;
+    } else if (hx == 0x3ff00000 && (ix << 32) == 0) {
+        return 0;
+    }
+    hx += 0x3ff00000 - 0x3fe6a09e;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffff) + 0x3fe6a09e;
+    ix = ((unsigned long long)hx << 32) | (ix & 0xffffffffull);
+    x = __longlong_as_double((long long)ix);
+    const double f = x - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double dk = k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+__device__ __forceinline__ bool is_odd_integer(double v) {
+    const double ip = trunc(v);
+    if (v - ip != 0) return false;
+    return fmod(ip, 2.0) != 0;
+}
+
+__device__ double zig_pow(double x, double y) {
+    const double inf = __builtin_huge_val();
+    if (y == 0 || x == 1) return 1;
+    if (x != x || y != y) return __builtin_nan("");
+    if (y == 1) return x;
+    if (x == 0) {
+        if (y < 0) return is_odd_integer(y) ? copysign(inf, x) : inf;
+        return is_odd_integer(y) ? x : 0.0;
+    }
+    if (isinf(y)) {
+        if (x == -1) return 1;
+        if ((fabs(x) < 1) == (y > 0)) return 0;
+        return inf;
+    }
+    if (isinf(x)) {
+        if (x < 0) {
+            if (y < 0) return is_odd_integer(y) ? -0.0 : 0.0;
+            return is_odd_integer(y) ? -inf : inf;
+        }
+        return y < 0 ? 0.0 : inf;
+    }
+    if (y == 0.5) return sqrt(x);
+    if (y == -0.5) return 1 / sqrt(x);
+
+    const double ay = fabs(y);
+    double yi = trunc(ay);
+    double yf = ay - yi;  // exact: modf's fractional part
+    if (yf != 0 && x < 0) return __builtin_nan("");
+    if (yi >= 9223372036854775808.0) return zig_exp(y * zig_ln(x));
+
+    double a1 = 1.0;
+    int ae = 0;
+    if (yf != 0) {
+        if (yf > 0.5) {
+            yf -= 1;
+            yi += 1;
+        }
+        a1 = zig_exp(yf * zig_ln(x));
+    }
+    int xe;
+    double x1 = frexp(x, &xe);
+    long long i = (long long)yi;
+    while (i != 0) {
+        if (xe < -(1 << 12) || (1 << 12) < xe) {
+            ae += xe;
+            break;
+        }
+        if (i & 1) {
+            a1 *= x1;
+            ae += xe;
+        }
+        x1 *= x1;
+        xe <<= 1;
+        if (x1 < 0.5) {
+            x1 += x1;
+            xe -= 1;
+        }
+        i >>= 1;
+    }
+    if (y < 0) {
+        a1 = 1 / a1;
+        ae = -ae;
+    }
+    return ldexp(a1, ae);
+}
+
+// ---------------------------------------------------------------------------------------
+// One sweep of a world ray over every shape: calc.intersectWorld (calc.zig:200-214) +
+// Intersections.hit (ray.zig:75-83) as a running minimum.
+//
+// The reference sorts all t values (stable) and takes the first with t >= 0; visiting the
+// shapes in list order, t1 before t2, and replacing the best only on strict < selects the
+// same element.  For n1/n2 (calc.zig:269-291) everything the reference's container walk
+// meets before the hit has t < 0, so the containers still open at the hit are the spheres
+// with t1 < 0 <= t2 and the planes with t < 0 (a plane behind the origin never closes),
+// ordered by entry t, ties by list order; only the innermost two can matter.
+struct Sweep {
+    double t;         // nearest t >= 0 (valid when idx >= 0)
+    int idx;          // shape index of the hit, -1 = miss
+    bool exit_open;   // the hit is t2 of a sphere whose t1 < 0 (that sphere is an open container)
+    int top1, top2;   // innermost and second innermost open container, -1 = none
+    double top1_t, top2_t;
+};
+
+template <bool CONTAINERS, bool STATS>
+__device__ __forceinline__ void sweep_world(const double* __restrict__ inv, const int32_t* __restrict__ geo, int n,
+                                            const V3& o, const V3& d, Sweep& s, uint32_t& sphere_hits,
+                                            uint32_t& plane_hits) {
+    s.idx = -1;
+    s.t = 0.0;
+    s.exit_open = false;
+    s.top1 = s.top2 = -1;
+    s.top1_t = s.top2_t = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double* __restrict__ m = inv + (size_t)i * 12;
+        if (geo[i] == RTC_GEO_SPHERE) {
+            // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
+            const V3 lo = xform_point(m, o);
+            const V3 ld = xform_dir(m, d);
+            const double a = dot3(ld, ld);
+            const double b = 2.0 * dot3(ld, lo);
+            const double c = dot3(lo, lo) - 1.0;
+            const double disc = b * b - 4.0 * a * c;
+            if (!(disc < 0)) {
+                if (STATS) ++sphere_hits;
+                const double sq = sqrt(disc);
+                const double den = 2.0 * a;
+                const double t1 = (-b - sq) / den;
+                const double t2 = (-b + sq) / den;
+                if (t1 >= 0) {
+                    // t2 >= t1 can never win under strict <
+                    if (s.idx < 0 || t1 < s.t) {
+                        s.idx = i;
+                        s.t = t1;
+                        s.exit_open = false;
+                    }
+                } else if (t2 >= 0) {
+                    if (CONTAINERS) {
+                        if (s.top1 < 0 || t1 >= s.top1_t) {
+                            s.top2 = s.top1;
+                            s.top2_t = s.top1_t;
+                            s.top1 = i;
+                            s.top1_t = t1;
+                        } else if (s.top2 < 0 || t1 >= s.top2_t) {
+                            s.top2 = i;
+                            s.top2_t = t1;
+                        }
+                    }
+                    if (s.idx < 0 || t2 < s.t) {
+                        s.idx = i;
+                        s.t = t2;
+                        s.exit_open = true;
+                    }
+                }
+            }
+        } else {
+            // Plane.localIntersect (shape.zig:55-70): only row 1 of the local ray is used
+            const double loy = ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7];
+            const double ldy = (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
+            if (!(fabs(ldy) < kF64Eps)) {
+                if (STATS) ++plane_hits;
+                const double t = -loy / ldy;
+                if (t >= 0) {
+                    if (s.idx < 0 || t < s.t) {
+                        s.idx = i;
+                        s.t = t;
+                        s.exit_open = false;
+                    }
+                } else if (CONTAINERS && t < 0) {
+                    if (s.top1 < 0 || t >= s.top1_t) {
+                        s.top2 = s.top1;
+                        s.top2_t = s.top1_t;
+                        s.top1 = i;
+                        s.top1_t = t;
+                    } else if (s.top2 < 0 || t >= s.top2_t) {
+                        s.top2 = i;
+                        s.top2_t = t;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Pattern.patternAt (pattern.zig:77-91) and the four pattern functions (pattern.zig:15-62)
+__device__ __forceinline__ V3 pattern_color(const DevShade& sh, const double* __restrict__ obj_inv, const V3& wp) {
+    const V3 op = xform_point(obj_inv, wp);
+    const V3 pp = xform_point(sh.pat_inv, op);
+    const V3 a = {sh.pat_a[0], sh.pat_a[1], sh.pat_a[2]};
+    const V3 b = {sh.pat_b[0], sh.pat_b[1], sh.pat_b[2]};
+    double c;
+    switch (sh.pattern) {
+        case RTC_PATTERN_POINT:
+            return pp;
+        case RTC_PATTERN_GRADIENT: {
+            const double fraction = pp.x - floor(pp.x);
+            // a.add(b.sub(a).scale(fraction))
+            return {a.x + fraction * (b.x - a.x), a.y + fraction * (b.y - a.y), a.z + fraction * (b.z - a.z)};
+        }
+        case RTC_PATTERN_STRIPE:
+            c = floor(pp.x);
+            break;
+        case RTC_PATTERN_RING:
+            c = floor(sqrt(pp.x * pp.x + pp.z * pp.z));
+            break;
+        default:  // checkers
+            c = (floor(pp.x) + floor(pp.y)) + floor(pp.z);
+            break;
+    }
+    // @mod(c, 2) == 0 on an integral value: even/odd test
+    return fmod(c, 2.0) == 0 ? a : b;
+}
+
+// Frame of a node whose children are still being traced.
+//   acc      surface colour, then surface + reflected term (calc.zig:466,468)
+//   refl     material.reflective (scales the reflected child, calc.zig:958)
+//   transp   material.transparency (scales the refracted child, calc.zig:852)
+//   R        Schlick reflectance when flags & kSchlick (calc.zig:464-466)
+//   ray      the refracted ray, parked while the reflected subtree is traced
+enum : int { kHasRefract = 1, kSchlick = 2, kWaitRefract = 4 };
+
+// The read-only tables and the output are separate __restrict__ kernel arguments so that
+// the compiler can prove the wave-uniform table reads are never clobbered by the kernel's
+// own stores and keep them on the scalar path; the structs carry the remaining scalars.
+template <int MAXD, bool STATS, bool FROM_RAYS>
+__global__ __launch_bounds__(kBlock) void render_kernel(const double* __restrict__ g_inv,
+                                                        const int32_t* __restrict__ g_geo,
+                                                        const DevShade* __restrict__ g_shade,
+                                                        const double* __restrict__ g_rays,
+                                                        double* __restrict__ g_out, uint32_t* __restrict__ g_counter,
+                                                        unsigned long long* __restrict__ g_stats, const DevWorld wc,
+                                                        const DevJob job) {
+    const int lane = (int)(threadIdx.x & 63);
+    DevWorld w = wc;
+    w.inv = g_inv;
+    w.geo = g_geo;
+    w.shade = g_shade;
+
+    // per-lane frame stack (private memory: touched once per node, a few dozen bytes)
+    double f_acc[MAXD][3];
+    double f_ray[MAXD][6];
+    double f_refl[MAXD], f_transp[MAXD], f_R[MAXD];
+    int f_flags[MAXD];
+
+    uint32_t n_radiance = 0, n_shadow = 0, n_sphere_hits = 0, n_plane_hits = 0, n_shaded = 0;
+
+    long long out_index = -1;  // < 0: lane holds no pixel
+    int sp = 0;
+    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
+    bool exhausted = false;  // wave-uniform
+
+    const V3 light = {w.light_pos[0], w.light_pos[1], w.light_pos[2]};
+    const V3 lint = {w.light_int[0], w.light_int[1], w.light_int[2]};
+
+    for (;;) {
+        // ---- hand new work to idle lanes ------------------------------------------------
+        const unsigned long long idle = __ballot(out_index < 0);
+        if (idle != 0 && !exhausted) {
+            const uint32_t cnt = (uint32_t)__popcll(idle);
+            uint32_t base = 0;
+            if (lane == (int)__ffsll((long long)idle) - 1) base = atomicAdd(g_counter, cnt);
+            base = (uint32_t)__shfl((int)base, (int)__ffsll((long long)idle) - 1);
+            if (base + cnt >= job.total || base + cnt < base) exhausted = true;
+            if (out_index < 0) {
+                const uint32_t rank_in_wave = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t k = base + rank_in_wave;
+                if (k < job.total && base + rank_in_wave >= base) {
+                    if (FROM_RAYS) {
+                        const double* r = g_rays + (size_t)k * 6;
+                        ro = {r[0], r[1], r[2]};
+                        rd = {r[3], r[4], r[5]};
+                        out_index = (long long)k * 3;
+                        sp = 0;
+                    } else {
+                        // tile order: k -> (local tile, pixel in tile) -> canvas (x, y)
+                        const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
+                        const uint32_t lt = k / tile_px, within = k % tile_px;
+                        const uint32_t gt = lt * job.tile_ranks + job.tile_rank;
+                        const uint32_t px = (gt % job.tiles_x) * RTC_TILE_W + within % RTC_TILE_W;
+                        const uint32_t py = (gt / job.tiles_x) * RTC_TILE_H + within / RTC_TILE_W;
+                        if (gt < job.tiles_total && px < job.hsize && py < job.vsize) {
+                            // Camera.rayForPixel (camera.zig:48-72)
+                            const double x_offset = ((double)px + 0.5) * job.pixel_size;
+                            const double y_offset = ((double)py + 0.5) * job.pixel_size;
+                            const double world_x = job.half_width - x_offset;
+                            const double world_y = job.half_height - y_offset;
+                            const V3 pixel = xform_point(job.cam_inv, V3{world_x, world_y, -1.0});
+                            const V3 origin = xform_point(job.cam_inv, V3{0.0, 0.0, 0.0});
+                            ro = origin;
+                            rd = normalize3(V3{pixel.x - origin.x, pixel.y - origin.y, pixel.z - origin.z});
+                            out_index = job.tile_ranks == 1 ? ((long long)py * job.hsize + px) * 3 : (long long)k * 3;
+                            sp = 0;
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(out_index >= 0) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+
+        if (out_index >= 0) {
+            // ---- one tree node: calc.worldColorAt (calc.zig:641-652) ---------------------
+            if (STATS) ++n_radiance;
+            const int remaining = job.depth - sp;
+            Sweep hit;
+            sweep_world<true, STATS>(g_inv, g_geo, w.n, ro, rd, hit, n_sphere_hits, n_plane_hits);
+
+            V3 ret = {0.0, 0.0, 0.0};  // Color.Black on a miss (calc.zig:650)
+            bool descend = false;
+            if (hit.idx >= 0) {
+                if (STATS) ++n_shaded;
+                const DevShade& sh = w.shade[hit.idx];
+                const double* __restrict__ oinv = w.inv + (size_t)hit.idx * 12;
+
+                // ---- calc.prepareComputations (calc.zig:247-306)
+                const V3 point = {ro.x + hit.t * rd.x, ro.y + hit.t * rd.y, ro.z + hit.t * rd.z};
+                const V3 eyev = {-rd.x, -rd.y, -rd.z};
+                // Shape.normalAt (shape.zig:84-97)
+                V3 ln;
+                if (sh.geo == RTC_GEO_SPHERE) {
+                    ln = normalize3(xform_point(oinv, point));
+                } else {
+                    ln = {0.0, 1.0, 0.0};
+                }
+                V3 normalv = normalize3(V3{(oinv[0] * ln.x + oinv[4] * ln.y) + oinv[8] * ln.z,
+                                           (oinv[1] * ln.x + oinv[5] * ln.y) + oinv[9] * ln.z,
+                                           (oinv[2] * ln.x + oinv[6] * ln.y) + oinv[10] * ln.z});
+                if (dot3(normalv, eyev) < 0) normalv = {-normalv.x, -normalv.y, -normalv.z};
+                const double two_dp = 2.0 * dot3(rd, normalv);  // Vec4.reflect, vector.zig:114-117
+                const V3 reflectv = {rd.x - two_dp * normalv.x, rd.y - two_dp * normalv.y, rd.z - two_dp * normalv.z};
+                const V3 offs = {kSurfaceEps * normalv.x, kSurfaceEps * normalv.y, kSurfaceEps * normalv.z};
+                const V3 over_point = {point.x + offs.x, point.y + offs.y, point.z + offs.z};
+                const V3 under_point = {point.x - offs.x, point.y - offs.y, point.z - offs.z};
+                // n1 / n2 from the open containers
+                const double n1 = hit.top1 < 0 ? 1.0 : w.shade[hit.top1].refractive_index;
+                double n2;
+                if (hit.exit_open) {
+                    const int rest = (hit.top1 == hit.idx) ? hit.top2 : hit.top1;
+                    n2 = rest < 0 ? 1.0 : w.shade[rest].refractive_index;
+                } else {
+                    n2 = sh.refractive_index;
+                }
+
+                // ---- calc.isShadowed (calc.zig:777-790) at over_point
+                if (STATS) ++n_shadow;
+                const V3 lv = {light.x - over_point.x, light.y - over_point.y, light.z - over_point.z};
+                const double distance = sqrt((lv.x * lv.x + lv.y * lv.y) + lv.z * lv.z);
+                const V3 lightv = {lv.x / distance, lv.y / distance, lv.z / distance};
+                Sweep sh_hit;
+                sweep_world<false, STATS>(g_inv, g_geo, w.n, over_point, lightv, sh_hit, n_sphere_hits, n_plane_hits);
+                const bool in_shadow = sh_hit.idx >= 0 && sh_hit.t < distance;
+
+                // ---- calc.lighting (calc.zig:26-73) at over_point; lightv above is the same
+                // light.position.sub(position).normalize() the reference recomputes
+                V3 color = {sh.color[0], sh.color[1], sh.color[2]};
+                if (sh.pattern >= 0) color = pattern_color(sh, oinv, over_point);
+                const V3 eff = {color.x * lint.x, color.y * lint.y, color.z * lint.z};
+                V3 surface = {sh.ambient * eff.x, sh.ambient * eff.y, sh.ambient * eff.z};
+                const double light_dot_normal = dot3(lightv, normalv);
+                if (light_dot_normal > 0.0 && !in_shadow) {
+                    const double kd = sh.diffuse * light_dot_normal;
+                    surface = {surface.x + kd * eff.x, surface.y + kd * eff.y, surface.z + kd * eff.z};
+                    const V3 nl = {-lightv.x, -lightv.y, -lightv.z};
+                    const double two_ln = 2.0 * dot3(nl, normalv);
+                    const V3 lr = {nl.x - two_ln * normalv.x, nl.y - two_ln * normalv.y, nl.z - two_ln * normalv.z};
+                    const double reflect_dot_eye = dot3(lr, eyev);
+                    if (reflect_dot_eye > 0.0) {
+                        const double ks = sh.specular * zig_pow(reflect_dot_eye, sh.shininess);
+                        surface = {surface.x + ks * lint.x, surface.y + ks * lint.y, surface.z + ks * lint.z};
+                    }
+                }
+
+                // ---- children: calc.reflectedColor (945-959), calc.refractedColor (828-853)
+                const bool has_reflect = remaining > 0 && !(fabs(sh.reflective) <= kF64Eps);
+                bool has_refract = false;
+                V3 refr_dir = {0, 0, 0};
+                const double cos_i = dot3(eyev, normalv);
+                if (remaining > 0 && !(fabs(sh.transparency) <= kF64Eps)) {
+                    const double n_ratio = n1 / n2;
+                    const double sin2_t = n_ratio * n_ratio * (1 - cos_i * cos_i);
+                    if (!(sin2_t > 1.0)) {
+                        const double cos_t = sqrt(1.0 - sin2_t);
+                        const double kn = n_ratio * cos_i - cos_t;
+                        refr_dir = {kn * normalv.x - n_ratio * eyev.x, kn * normalv.y - n_ratio * eyev.y,
+                                    kn * normalv.z - n_ratio * eyev.z};
+                        has_refract = true;
+                    }
+                }
+                int flags = has_refract ? kHasRefract : 0;
+                double R = 0.0;
+                if (sh.reflective > 0.0 && sh.transparency > 0.0) {
+                    // calc.schlick (calc.zig:1004-1026)
+                    flags |= kSchlick;
+                    double cosv = cos_i;
+                    bool tir = false;
+                    if (n1 > n2) {
+                        const double nn = n1 / n2;
+                        const double sin2_t = nn * nn * (1.0 - cosv * cosv);
+                        if (sin2_t > 1.0)
+                            tir = true;
+                        else
+                            cosv = sqrt(1.0 - sin2_t);
+                    }
+                    if (tir) {
+                        R = 1.0;
+                    } else {
+                        const double r0 = zig_pow((n1 - n2) / (n1 + n2), 2.0);
+                        R = r0 + (1 - r0) * zig_pow(1 - cosv, 5.0);
+                    }
+                }
+                if (has_reflect || has_refract) {
+                    f_acc[sp][0] = surface.x;
+                    f_acc[sp][1] = surface.y;
+                    f_acc[sp][2] = surface.z;
+                    f_refl[sp] = sh.reflective;
+                    f_transp[sp] = sh.transparency;
+                    f_R[sp] = R;
+                    if (has_reflect) {
+                        f_ray[sp][0] = under_point.x;
+                        f_ray[sp][1] = under_point.y;
+                        f_ray[sp][2] = under_point.z;
+                        f_ray[sp][3] = refr_dir.x;
+                        f_ray[sp][4] = refr_dir.y;
+                        f_ray[sp][5] = refr_dir.z;
+                        f_flags[sp] = flags;
+                        ro = over_point;
+                        rd = reflectv;
+                    } else {
+                        // no reflected child: its term is Color.Black and adds nothing
+                        f_flags[sp] = flags | kWaitRefract;
+                        ro = under_point;
+                        rd = refr_dir;
+                    }
+                    ++sp;
+                    descend = true;
+                } else if (flags & kSchlick) {
+                    // surface + Black.scale(R) + Black.scale(1 - R): a non-finite R must poison the colour
+                    const double zr = R * 0.0, zt = (1.0 - R) * 0.0;
+                    ret = {(surface.x + zr) + zt, (surface.y + zr) + zt, (surface.z + zr) + zt};
+                } else {
+                    ret = surface;  // surface + Black + Black
+                }
+            }
+
+            // ---- unwind finished subtrees in the reference's post-order -------------------
+            if (!descend) {
+                while (sp > 0) {
+                    const int f = sp - 1;
+                    const int flags = f_flags[f];
+                    if (!(flags & kWaitRefract)) {
+                        // reflected child returned: color.scale(reflective) [.scale(reflectance)]
+                        const double kr = f_refl[f];
+                        V3 c = {kr * ret.x, kr * ret.y, kr * ret.z};
+                        if (flags & kSchlick) {
+                            const double R = f_R[f];
+                            c = {R * c.x, R * c.y, R * c.z};
+                        }
+                        const V3 acc = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
+                        if (flags & kHasRefract) {
+                            f_acc[f][0] = acc.x;
+                            f_acc[f][1] = acc.y;
+                            f_acc[f][2] = acc.z;
+                            f_flags[f] = flags | kWaitRefract;
+                            ro = {f_ray[f][0], f_ray[f][1], f_ray[f][2]};
+                            rd = {f_ray[f][3], f_ray[f][4], f_ray[f][5]};
+                            descend = true;
+                            break;
+                        }
+                        ret = acc;  // + Black refracted term
+                        --sp;
+                    } else {
+                        // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
+                        const double kt = f_transp[f];
+                        V3 c = {kt * ret.x, kt * ret.y, kt * ret.z};
+                        if (flags & kSchlick) {
+                            const double T = 1.0 - f_R[f];
+                            c = {T * c.x, T * c.y, T * c.z};
+                        }
+                        ret = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
+                        --sp;
+                    }
+                }
+                if (!descend) {
+                    // canvas.set (canvas.zig:24-28)
+                    g_out[out_index + 0] = ret.x;
+                    g_out[out_index + 1] = ret.y;
+                    g_out[out_index + 2] = ret.z;
+                    out_index = -1;
+                }
+            }
+        }
+    }
+
+    if (STATS) {
+        // one atomic per counter per wave
+        uint32_t v[5] = {n_radiance, n_shadow, n_sphere_hits, n_plane_hits, n_shaded};
+        for (int c = 0; c < 5; ++c) {
+            unsigned long long sum = v[c];
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+            if (lane == 0) atomicAdd(&g_stats[c], sum);
+        }
+    }
+}
+
+// Scatter gathered per-rank tile buffers into the row-major canvas.
+__global__ __launch_bounds__(kBlock) void deinterleave_kernel(const double* __restrict__ gathered,
+                                                              uint64_t per_rank_doubles, uint32_t tile_ranks,
+                                                              uint32_t hsize, uint32_t vsize, uint32_t tiles_x,
+                                                              uint32_t tiles_total, double* __restrict__ out) {
+    const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
+    const uint64_t total = (uint64_t)tiles_total * tile_px;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t gt = (uint32_t)(g / tile_px), within = (uint32_t)(g % tile_px);
+        const uint32_t px = (gt % tiles_x) * RTC_TILE_W + within % RTC_TILE_W;
+        const uint32_t py = (gt / tiles_x) * RTC_TILE_H + within / RTC_TILE_W;
+        if (px >= hsize || py >= vsize) continue;
+        const uint32_t rank = gt % tile_ranks, lt = gt / tile_ranks;
+        const double* src = gathered + (uint64_t)rank * per_rank_doubles + ((uint64_t)lt * tile_px + within) * 3;
+        double* dst = out + ((uint64_t)py * hsize + px) * 3;
+        dst[0] = src[0];
+        dst[1] = src[1];
+        dst[2] = src[2];
+    }
+}
+
+// byteColorValue (ppm.zig:6-9): clamp(v*256, 0, 255) with Zig's min/max, then truncate.
+__global__ __launch_bounds__(kBlock) void quantize_kernel(const double* __restrict__ rgb, uint64_t n,
+                                                          uint8_t* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        double v = rgb[i] * 256.0;
+        v = v < 255.0 ? v : 255.0;
+        v = v > 0.0 ? v : 0.0;
+        out[i] = (uint8_t)v;
+    }
+}
+
+// a/b, sqrt(a) and pow(a,b) element-wise, for bit-level comparison against the host.
+__global__ __launch_bounds__(kBlock) void arith_probe_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                                                             uint64_t n, double* __restrict__ out_div,
+                                                             double* __restrict__ out_sqrt, double* __restrict__ out_pow) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        out_div[i] = a[i] / b[i];
+        out_sqrt[i] = sqrt(a[i]);
+        out_pow[i] = zig_pow(a[i], b[i]);
+    }
+}
+
+template <int MAXD, bool STATS, bool FROM_RAYS>
+hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t stream) {
+    auto kernel = render_kernel<MAXD, STATS, FROM_RAYS>;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    int cus = 0;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    uint64_t blocks = (uint64_t)cus * (uint64_t)per_cu;
+    const uint64_t needed = ((uint64_t)job.total + kBlock - 1) / kBlock;
+    if (blocks > needed) blocks = needed;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.inv, world.geo, world.shade,
+                       job.rays, job.out, job.counter, (unsigned long long*)job.stats, world, job);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_render(const DevWorld& world, const DevJob& job, bool with_stats, hipStream_t stream) {
+    const bool rays = job.rays != nullptr;
+    const bool small = job.depth <= kMaxDepthSmall;
+    if (small) {
+        if (with_stats) return rays ? launch_variant<kMaxDepthSmall, true, true>(world, job, stream)
+                                    : launch_variant<kMaxDepthSmall, true, false>(world, job, stream);
+        return rays ? launch_variant<kMaxDepthSmall, false, true>(world, job, stream)
+                    : launch_variant<kMaxDepthSmall, false, false>(world, job, stream);
+    }
+    if (with_stats) return rays ? launch_variant<kMaxDepthLarge, true, true>(world, job, stream)
+                                : launch_variant<kMaxDepthLarge, true, false>(world, job, stream);
+    return rays ? launch_variant<kMaxDepthLarge, false, true>(world, job, stream)
+                : launch_variant<kMaxDepthLarge, false, false>(world, job, stream);
+}
+
+hipError_t launch_deinterleave(const double* gathered, uint64_t per_rank_doubles, uint32_t tile_ranks, uint32_t hsize,
+                               uint32_t vsize, double* out, hipStream_t stream) {
+    const uint32_t tiles_x = (hsize + RTC_TILE_W - 1) / RTC_TILE_W;
+    const uint32_t tiles_y = (vsize + RTC_TILE_H - 1) / RTC_TILE_H;
+    const uint32_t tiles_total = tiles_x * tiles_y;
+    const uint64_t total = (uint64_t)tiles_total * RTC_TILE_W * RTC_TILE_H;
+    uint64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, gathered, per_rank_doubles,
+                       tile_ranks, hsize, vsize, tiles_x, tiles_total, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize(const double* rgb, uint64_t n, uint8_t* out, hipStream_t stream) {
+    uint64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, rgb, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_arith_probe(const double* a, const double* b, uint64_t n, double* out_div, double* out_sqrt,
+                              double* out_pow, hipStream_t stream) {
+    uint64_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(arith_probe_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, b, n, out_div, out_sqrt,
+                       out_pow);
+    return hipGetLastError();
+}
+
+}  // namespace rtc

@@ -1,0 +1,176 @@
+"""ctypes binding of librtc_hip.so (the C-ABI of include/rtc_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or a call returns a non-zero
+status, an exception is raised.  torch is not needed here; callers that keep buffers on
+the device pass raw device pointers (e.g. tensor.data_ptr()) and stream handles.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import descs as D
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtc_hip.so")
+_lib = None
+
+
+class RtcError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"rtc error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load librtc_hip.so once.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `make -C raytracer_challenge_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback for the render path"
+        )
+    L = C.CDLL(_LIB_PATH)
+    dp, u64, u32, i32, vp = C.POINTER(C.c_double), C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p
+    L.rtc_last_error.restype = C.c_char_p
+    L.rtc_last_error.argtypes = []
+    L.rtc_device_count.argtypes = [C.POINTER(i32)]
+    L.rtc_set_device.argtypes = [i32]
+    L.rtc_scene_create.argtypes = [C.POINTER(D.RtcShapeDesc), u64, C.POINTER(D.RtcLightDesc), C.POINTER(vp)]
+    L.rtc_scene_destroy.argtypes = [vp]
+    L.rtc_render.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, dp, C.POINTER(D.RtcStats)]
+    L.rtc_render_device.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
+    L.rtc_tile_buffer_doubles.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, C.POINTER(u64)]
+    L.rtc_deinterleave_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
+    L.rtc_color_at.argtypes = [vp, dp, u64, i32, dp, C.POINTER(D.RtcStats)]
+    L.rtc_quantize_u8_device.argtypes = [vp, u64, vp, vp]
+    L.rtc_mat4_inverse.argtypes = [dp, dp, dp]
+    L.rtc_arith_probe.argtypes = [dp, dp, u64, dp, dp, dp]
+    for name in EXPORTS:
+        if name != "rtc_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+# every symbol include/rtc_hip.h declares
+EXPORTS = (
+    "rtc_last_error",
+    "rtc_device_count",
+    "rtc_set_device",
+    "rtc_scene_create",
+    "rtc_scene_destroy",
+    "rtc_render",
+    "rtc_render_device",
+    "rtc_tile_buffer_doubles",
+    "rtc_deinterleave_device",
+    "rtc_color_at",
+    "rtc_quantize_u8_device",
+    "rtc_mat4_inverse",
+    "rtc_arith_probe",
+)
+
+
+def check(code):
+    if code != D.RTC_OK:
+        raise RtcError(code, lib().rtc_last_error().decode("utf-8", "replace"))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(lib().rtc_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(i):
+    check(lib().rtc_set_device(int(i)))
+
+
+def mat4_inverse(m16):
+    m = np.ascontiguousarray(np.asarray(m16, dtype=np.float64).reshape(16))
+    out = np.empty(16, dtype=np.float64)
+    det = C.c_double(0)
+    check(lib().rtc_mat4_inverse(_dptr(m), _dptr(out), C.byref(det)))
+    return out.reshape(4, 4), det.value
+
+
+def arith_probe(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    assert a.shape == b.shape and a.ndim == 1
+    q, s, p = (np.empty_like(a) for _ in range(3))
+    check(lib().rtc_arith_probe(_dptr(a), _dptr(b), a.size, _dptr(q), _dptr(s), _dptr(p)))
+    return q, s, p
+
+
+def tile_buffer_doubles(camera_desc, tile_rank, tile_ranks):
+    n = C.c_uint64(0)
+    check(lib().rtc_tile_buffer_doubles(C.byref(camera_desc), tile_rank, tile_ranks, C.byref(n)))
+    return n.value
+
+
+def deinterleave_device(camera_desc, tile_ranks, per_rank_doubles, d_gathered, d_out, stream=None):
+    check(lib().rtc_deinterleave_device(C.byref(camera_desc), tile_ranks, per_rank_doubles, d_gathered, d_out, stream))
+
+
+def quantize_u8_device(d_rgb, n_values, d_out_u8, stream=None):
+    check(lib().rtc_quantize_u8_device(d_rgb, n_values, d_out_u8, stream))
+
+
+class Scene:
+    """An uploaded world (rtc_scene_create / rtc_scene_destroy)."""
+
+    def __init__(self, shape_descs, n_shapes, light_desc):
+        self._h = C.c_void_p(None)
+        check(lib().rtc_scene_create(shape_descs, int(n_shapes), C.byref(light_desc), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().rtc_scene_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, camera_desc, depth=5, stats=None):
+        """rtc_render: returns the canvas as a (vsize, hsize, 3) float64 array."""
+        out = np.empty((camera_desc.vsize, camera_desc.hsize, 3), dtype=np.float64)
+        sp = C.byref(stats) if stats is not None else None
+        check(lib().rtc_render(self._h, C.byref(camera_desc), int(depth), _dptr(out), sp))
+        return out
+
+    def render_device(self, camera_desc, depth, d_out, tile_rank=0, tile_ranks=1, stream=None, stats=None):
+        """rtc_render_device: d_out is a raw device pointer (int)."""
+        sp = C.byref(stats) if stats is not None else None
+        check(
+            lib().rtc_render_device(
+                self._h, C.byref(camera_desc), int(depth), tile_rank, tile_ranks, C.c_void_p(d_out), stream, sp
+            )
+        )
+
+    def color_at(self, rays, depth=5, stats=None):
+        """rtc_color_at: rays is (n, 6) [origin xyz, direction xyz]; returns (n, 3)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        out = np.empty((rays.shape[0], 3), dtype=np.float64)
+        sp = C.byref(stats) if stats is not None else None
+        check(lib().rtc_color_at(self._h, _dptr(rays), rays.shape[0], int(depth), _dptr(out), sp))
+        return out
