@@ -1,0 +1,89 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol the header declares,
+its descriptor structs have the layout the Python binding assumes, and its host-only logic
+(the cofactor inverse used at scene upload, argument validation) matches the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracer_challenge_amd import descs as D, native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rtc_hip.h")
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(rtc_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(native.EXPORTS), declared ^ set(native.EXPORTS)
+    L = native.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_struct_layout_matches_the_c_compiler():
+    names = ["RtcPatternDesc", "RtcMaterialDesc", "RtcShapeDesc", "RtcLightDesc", "RtcCameraDesc", "RtcStats"]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "rtc_hip.h"\nint main(void){' + "".join(
+        f'printf("%zu\\n", sizeof({n}));' for n in names) + (
+        'printf("%zu %zu %zu\\n", offsetof(RtcShapeDesc, transform), offsetof(RtcShapeDesc, material),'
+        ' offsetof(RtcMaterialDesc, pattern));return 0;}')
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
+    sizes = [int(v) for v in out[:6]]
+    assert sizes == [C.sizeof(getattr(D, n)) for n in names]
+    assert [int(v) for v in out[6:]] == [D.RtcShapeDesc.transform.offset, D.RtcShapeDesc.material.offset,
+                                          D.RtcMaterialDesc.pattern.offset]
+
+
+def test_host_inverse_is_bit_identical_to_the_oracle():
+    rng = np.random.default_rng(7)
+    for i in range(300):
+        m = np.eye(4)
+        m[:3, :] = rng.uniform(-3, 3, (3, 4))
+        if i % 3 == 0:
+            m = rng.uniform(-3, 3, (4, 4))  # general matrices too: the routine itself is generic
+        inv_p, det_p = native.mat4_inverse(m)
+        inv_o, det_o = O.mat4_inverse(m)
+        assert det_p == det_o
+        assert np.array_equal(inv_p, inv_o)
+
+
+def test_reference_inverse_known_answer():  # matrix.zig:620-648
+    a = [[-5, 2, 6, -8], [1, -5, 1, 8], [7, 7, -6, -7], [1, -3, 7, 4]]
+    inv, det = native.mat4_inverse(a)
+    assert det == 532.0
+    assert inv[3, 2] == -160.0 / 532.0 and inv[2, 3] == 105.0 / 532.0
+    exp = [[0.21805, 0.45113, 0.24060, -0.04511], [-0.80827, -1.45677, -0.44361, 0.52068],
+           [-0.07895, -0.22368, -0.05263, 0.19737], [-0.52256, -0.81391, -0.30075, 0.30639]]
+    assert np.allclose(inv, exp, atol=1e-5)
+
+
+def test_singular_matrix_is_rejected():  # matrix.zig:606-618, :288
+    with pytest.raises(native.RtcError) as e:
+        native.mat4_inverse([[-4, 2, -2, -3], [9, 6, 2, 6], [0, -5, 1, -5], [0, 0, 0, 0]])
+    assert e.value.code == D.RTC_ERR_SINGULAR_TRANSFORM
+
+
+def test_argument_validation_needs_no_gpu():
+    L = native.lib()
+    n = C.c_uint64(0)
+    cam = D.RtcCameraDesc()
+    assert L.rtc_tile_buffer_doubles(C.byref(cam), 0, 1, C.byref(n)) == D.RTC_ERR_INVALID_ARGUMENT  # 0x0 canvas
+    assert b"hsize" in L.rtc_last_error()
+    cam.hsize, cam.vsize = 900, 450
+    assert L.rtc_tile_buffer_doubles(C.byref(cam), 2, 2, C.byref(n)) == D.RTC_ERR_INVALID_ARGUMENT
+    assert L.rtc_tile_buffer_doubles(C.byref(cam), 0, 1, C.byref(n)) == D.RTC_OK and n.value == 900 * 450 * 3
+    assert L.rtc_tile_buffer_doubles(C.byref(cam), 1, 2, C.byref(n)) == D.RTC_OK
+    assert n.value == ((15 * 57) // 2) * 64 * 8 * 3
+    h = C.c_void_p()
+    assert L.rtc_scene_create(None, 3, None, C.byref(h)) == D.RTC_ERR_INVALID_ARGUMENT
