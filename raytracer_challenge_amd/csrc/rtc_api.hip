@@ -175,8 +175,7 @@ struct RtcScene {
     int device = 0;
     uint64_t n = 0;
     uint64_t n_spheres = 0, n_planes = 0;
-    double* d_inv = nullptr;
-    int32_t* d_geo = nullptr;
+    double* d_tab = nullptr;
     rtc::DevShade* d_shade = nullptr;
     uint32_t* d_counter = nullptr;  // work-queue head (4 B) followed by 5 x uint64 stats
     uint64_t* d_stats = nullptr;
@@ -189,8 +188,7 @@ namespace {
 
 void free_scene(RtcScene* s) {
     if (!s) return;
-    if (s->d_inv) (void)hipFree(s->d_inv);
-    if (s->d_geo) (void)hipFree(s->d_geo);
+    if (s->d_tab) (void)hipFree(s->d_tab);
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
@@ -200,8 +198,7 @@ void free_scene(RtcScene* s) {
 
 rtc::DevWorld dev_world(const RtcScene* s) {
     rtc::DevWorld w{};
-    w.inv = s->d_inv;
-    w.geo = s->d_geo;
+    w.tab = s->d_tab;
     w.shade = s->d_shade;
     w.n = (int32_t)s->n;
     for (int i = 0; i < 3; ++i) {
@@ -330,8 +327,8 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     if (!(light->position[3] == 1.0))
         return fail(RTC_ERR_INVALID_ARGUMENT, "light.position must be a point (w == 1)");
 
-    std::vector<double> inv(n_shapes * 12);
-    std::vector<int32_t> geo(n_shapes);
+    constexpr size_t kRec = 16;  // doubles per sweep-table record, see DevWorld
+    std::vector<double> tab((n_shapes + 1) * kRec, 0.0);
     std::vector<rtc::DevShade> shade(n_shapes);
     uint64_t n_spheres = 0, n_planes = 0;
     std::unordered_map<uint64_t, std::vector<uint64_t>> buckets;
@@ -345,8 +342,9 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         (s.geo == RTC_GEO_SPHERE ? n_spheres : n_planes)++;
         double full[16];
         if (int rc = invert_affine(s.transform, full, "shape", i)) return rc;
-        std::memcpy(&inv[i * 12], full, 12 * sizeof(double));
-        geo[i] = s.geo;
+        std::memcpy(&tab[i * kRec], full, 12 * sizeof(double));
+        const int64_t geo_word = s.geo;
+        std::memcpy(&tab[i * kRec + 12], &geo_word, sizeof geo_word);
         rtc::DevShade& d = shade[i];
         std::memset(&d, 0, sizeof d);
         const RtcMaterialDesc& m = s.material;
@@ -415,18 +413,15 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
             return fail_hip(#expr, _e); \
         }                               \
     } while (0)
-    SCENE_TRY(hipMalloc((void**)&sc->d_inv, n_alloc * 12 * sizeof(double)));
-    SCENE_TRY(hipMalloc((void**)&sc->d_geo, n_alloc * sizeof(int32_t)));
+    SCENE_TRY(hipMalloc((void**)&sc->d_tab, tab.size() * sizeof(double)));
     SCENE_TRY(hipMalloc((void**)&sc->d_shade, n_alloc * sizeof(rtc::DevShade)));
-    SCENE_TRY(hipMalloc((void**)&sc->d_counter, 64));
+    SCENE_TRY(hipMalloc((void**)&sc->d_counter, 64 + 3 * 8 * 8192));  // queue head, stats, developer probe area
     sc->d_stats = (uint64_t*)((char*)sc->d_counter + 8);
     SCENE_TRY(hipEventCreate(&sc->ev_start));
     SCENE_TRY(hipEventCreate(&sc->ev_stop));
-    if (n_shapes) {
-        SCENE_TRY(hipMemcpy(sc->d_inv, inv.data(), n_shapes * 12 * sizeof(double), hipMemcpyHostToDevice));
-        SCENE_TRY(hipMemcpy(sc->d_geo, geo.data(), n_shapes * sizeof(int32_t), hipMemcpyHostToDevice));
+    SCENE_TRY(hipMemcpy(sc->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (n_shapes)
         SCENE_TRY(hipMemcpy(sc->d_shade, shade.data(), n_shapes * sizeof(rtc::DevShade), hipMemcpyHostToDevice));
-    }
 #undef SCENE_TRY
     *out_scene = sc;
     return RTC_OK;
@@ -557,6 +552,14 @@ int rtc_arith_probe(const double* a, const double* b, uint64_t n, double* out_di
     (void)hipFree(d);
     return rc;
 }
+
+#ifdef RTC_PROBE
+int rtc_debug_probe(RtcScene* scene, uint64_t* out, uint64_t n_waves) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, (char*)scene->d_counter + 64, n_waves * 24, hipMemcpyDeviceToHost));
+    return RTC_OK;
+}
+#endif
 
 int rtc_mat4_inverse(const double* m, double* out_inv, double* out_det) {
     if (!m || !out_inv) return fail(RTC_ERR_INVALID_ARGUMENT, "NULL pointer");

@@ -29,13 +29,13 @@ struct DevShade {
 // Device-side view of an uploaded world.
 //
 // Layout in HBM (all allocated once per scene, read-only while rendering):
-//   inv   : n x 12 doubles — rows 0..2 of inverse(shape.transform), row-major 3x4.  The
-//           sweep reads it with wave-uniform addresses; 96 B per shape.
-//   geo   : n x int32      — RTC_GEO_* per shape, same order.
+//   tab   : (n+1) x 16 doubles, one 128-byte record per shape in list order: [0..11] rows
+//           0..2 of inverse(shape.transform), row-major 3x4; [12] the RTC_GEO_* tag (as the
+//           low bits of the word); [13..15] padding.  The sweep reads it with wave-uniform
+//           addresses, one record ahead, so record n exists as padding.
 //   shade : n x DevShade   — gathered per lane at a hit.
 struct DevWorld {
-    const double* inv;
-    const int32_t* geo;
+    const double* tab;
     const DevShade* shade;
     int32_t n;
     double light_pos[3];

@@ -31,6 +31,9 @@ namespace {
 constexpr double kF64Eps = 2.220446049250313080847263336181640625e-16;  // std.math.epsilon(f64)
 constexpr double kSurfaceEps = 0.0001;                                   // calc.zig:262
 constexpr int kBlock = 256;
+#ifndef RTC_WAVES_PER_EU
+#define RTC_WAVES_PER_EU 4  // minimum waves per SIMD the register allocation must allow (<= 128 VGPRs)
+#endif
 
 struct V3 {
     double x, y, z;
@@ -215,63 +218,107 @@ __device__ double zig_pow(double x, double y) {
 // meets before the hit has t < 0, so the containers still open at the hit are the spheres
 // with t1 < 0 <= t2 and the planes with t < 0 (a plane behind the origin never closes),
 // ordered by entry t, ties by list order; only the innermost two can matter.
+//
+// The quadratic's coefficients (54 flops per sphere) and the plane's two row products (11)
+// are always evaluated exactly as the reference does.  The roots (a square root and two
+// divisions; one division for a plane) are only needed when they can change the outcome,
+// so they are skipped when cheap bounds PROVE that the correctly rounded roots the reference
+// would compute lie entirely behind the origin or beyond the best hit so far:
+//   sphere behind   b > 0 and disc < b*b*(1-2^-40)  =>  sqrt(disc) < b  =>  t1 <= t2 < 0
+//   sphere beyond   L = (-b - best*den) - 2^-40*(|b| + best*den) > 0 and L*L > disc*(1+2^-40)
+//                   =>  (-b - sqrt(disc))/den > best by a margin of 2^-41 relative, far more
+//                   than the few-ulp rounding of the reference's expression  =>  t2 >= t1 > best
+//   plane beyond    |oy| > best*|dy|*(1+2^-40)  =>  t > best
+//   plane behind    oy and dy of equal sign  =>  t < 0 (only a container, irrelevant for a
+//                   shadow ray)
+// A skipped root can neither become the hit nor (being > best >= 0, or closed again) an open
+// container, so the result is unchanged.  The bounds assume t does not underflow to zero.
 struct Sweep {
-    double t;         // nearest t >= 0 (valid when idx >= 0)
+    double t;         // nearest t >= 0 (valid when idx >= 0); for a shadow sweep: starts at the light distance
     int idx;          // shape index of the hit, -1 = miss
     bool exit_open;   // the hit is t2 of a sphere whose t1 < 0 (that sphere is an open container)
     int top1, top2;   // innermost and second innermost open container, -1 = none
     double top1_t, top2_t;
 };
 
-template <bool CONTAINERS, bool STATS>
-__device__ __forceinline__ void sweep_world(const double* __restrict__ inv, const int32_t* __restrict__ geo, int n,
-                                            const V3& o, const V3& d, Sweep& s, uint32_t& sphere_hits,
-                                            uint32_t& plane_hits) {
+constexpr int kRecDoubles = 16;  // one shape record: 12 matrix entries, the geo tag, padding (128 B)
+constexpr double kOneMinus = 1.0 - 0x1p-40;
+constexpr double kOnePlus = 1.0 + 0x1p-40;
+
+struct ShapeRec {
+    double m[12];
+    long long geo;
+};
+// Wave-uniform read of record i (scalar loads); record n is padding so that reading one
+// record ahead is always in bounds.
+__device__ __forceinline__ ShapeRec load_rec(const double* __restrict__ tab, int i) {
+    ShapeRec r;
+    const double* __restrict__ p = tab + (size_t)i * kRecDoubles;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) r.m[k] = p[k];
+    r.geo = __double_as_longlong(p[12]);
+    return r;
+}
+
+__device__ __forceinline__ void push_container(Sweep& s, double t, int i) {
+    // ascending shape index: >= keeps the later shape on equal t, as the stable sort does
+    const bool first = s.top1 < 0 || t >= s.top1_t;
+    const bool second = !first && (s.top2 < 0 || t >= s.top2_t);
+    s.top2 = first ? s.top1 : (second ? i : s.top2);
+    s.top2_t = first ? s.top1_t : (second ? t : s.top2_t);
+    s.top1 = first ? i : s.top1;
+    s.top1_t = first ? t : s.top1_t;
+}
+
+// SHADOW: s.t holds the distance to the light on entry and only roots in [0, s.t) are
+// accepted (calc.zig:789: hit.t < distance); containers are not tracked.
+template <bool SHADOW, bool STATS>
+__device__ __forceinline__ void sweep_world(const double* __restrict__ tab, int n, const V3& o, const V3& d, Sweep& s,
+                                            uint32_t& sphere_hits, uint32_t& plane_hits) {
     s.idx = -1;
-    s.t = 0.0;
+    if (!SHADOW) s.t = 0.0;
     s.exit_open = false;
     s.top1 = s.top2 = -1;
     s.top1_t = s.top2_t = 0.0;
+    ShapeRec cur = load_rec(tab, 0);
     for (int i = 0; i < n; ++i) {
-        const double* __restrict__ m = inv + (size_t)i * 12;
-        if (geo[i] == RTC_GEO_SPHERE) {
+        // Scalar loads return out of order, so the only wait is "all of them".  Consume the
+        // current record first (that wait covers only its own loads), then request the next
+        // one, which stays in flight during this shape's arithmetic.
+        asm volatile("" ::"s"(cur.geo) : "memory");
+        const ShapeRec nxt = load_rec(tab, i + 1);
+        const double* m = cur.m;
+        const bool have = SHADOW || s.idx >= 0;
+        if (cur.geo == RTC_GEO_SPHERE) {
             // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
             const V3 lo = xform_point(m, o);
             const V3 ld = xform_dir(m, d);
             const double a = dot3(ld, ld);
             const double b = 2.0 * dot3(ld, lo);
             const double c = dot3(lo, lo) - 1.0;
-            const double disc = b * b - 4.0 * a * c;
+            const double bb = b * b;
+            const double disc = bb - 4.0 * a * c;
             if (!(disc < 0)) {
                 if (STATS) ++sphere_hits;
-                const double sq = sqrt(disc);
                 const double den = 2.0 * a;
-                const double t1 = (-b - sq) / den;
-                const double t2 = (-b + sq) / den;
-                if (t1 >= 0) {
-                    // t2 >= t1 can never win under strict <
-                    if (s.idx < 0 || t1 < s.t) {
-                        s.idx = i;
-                        s.t = t1;
-                        s.exit_open = false;
-                    }
-                } else if (t2 >= 0) {
-                    if (CONTAINERS) {
-                        if (s.top1 < 0 || t1 >= s.top1_t) {
-                            s.top2 = s.top1;
-                            s.top2_t = s.top1_t;
-                            s.top1 = i;
-                            s.top1_t = t1;
-                        } else if (s.top2 < 0 || t1 >= s.top2_t) {
-                            s.top2 = i;
-                            s.top2_t = t1;
-                        }
-                    }
-                    if (s.idx < 0 || t2 < s.t) {
-                        s.idx = i;
-                        s.t = t2;
-                        s.exit_open = true;
-                    }
+                bool need = !(b > 0 && disc < bb * kOneMinus);
+                if (have) {
+                    const double bd = s.t * den;
+                    const double L = (-b - bd) - 0x1p-40 * (fabs(b) + bd);
+                    need = need && !(L > 0 && L * L > disc * kOnePlus);
+                }
+                if (need) {
+                    const double sq = sqrt(disc);
+                    const double t1 = (-b - sq) / den;
+                    const double t2 = (-b + sq) / den;
+                    const bool in1 = t1 >= 0;
+                    const bool in2 = !in1 && t2 >= 0;  // t2 >= t1 never beats t1 under strict <
+                    const double cand = in1 ? t1 : t2;
+                    const bool better = (in1 || in2) && (!have || cand < s.t);
+                    s.t = better ? cand : s.t;
+                    s.idx = better ? i : s.idx;
+                    s.exit_open = better ? in2 : s.exit_open;
+                    if (!SHADOW && in2) push_container(s, t1, i);
                 }
             }
         } else {
@@ -280,26 +327,24 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ inv, cons
             const double ldy = (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
             if (!(fabs(ldy) < kF64Eps)) {
                 if (STATS) ++plane_hits;
-                const double t = -loy / ldy;
-                if (t >= 0) {
-                    if (s.idx < 0 || t < s.t) {
-                        s.idx = i;
-                        s.t = t;
-                        s.exit_open = false;
-                    }
-                } else if (CONTAINERS && t < 0) {
-                    if (s.top1 < 0 || t >= s.top1_t) {
-                        s.top2 = s.top1;
-                        s.top2_t = s.top1_t;
-                        s.top1 = i;
-                        s.top1_t = t;
-                    } else if (s.top2 < 0 || t >= s.top2_t) {
-                        s.top2 = i;
-                        s.top2_t = t;
-                    }
+                const bool behind = (loy < 0) == (ldy < 0) && loy != 0;
+                bool need;
+                if (behind)
+                    need = !SHADOW;
+                else
+                    need = !(have && fabs(loy) > (s.t * fabs(ldy)) * kOnePlus);
+                if (need) {
+                    const double t = -loy / ldy;
+                    const bool in = t >= 0;
+                    const bool better = in && (!have || t < s.t);
+                    s.t = better ? t : s.t;
+                    s.idx = better ? i : s.idx;
+                    s.exit_open = better ? false : s.exit_open;
+                    if (!SHADOW && t < 0) push_container(s, t, i);
                 }
             }
         }
+        cur = nxt;
     }
 }
 
@@ -344,8 +389,7 @@ enum : int { kHasRefract = 1, kSchlick = 2, kWaitRefract = 4 };
 // the compiler can prove the wave-uniform table reads are never clobbered by the kernel's
 // own stores and keep them on the scalar path; the structs carry the remaining scalars.
 template <int MAXD, bool STATS, bool FROM_RAYS>
-__global__ __launch_bounds__(kBlock) void render_kernel(const double* __restrict__ g_inv,
-                                                        const int32_t* __restrict__ g_geo,
+__global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const double* __restrict__ g_tab,
                                                         const DevShade* __restrict__ g_shade,
                                                         const double* __restrict__ g_rays,
                                                         double* __restrict__ g_out, uint32_t* __restrict__ g_counter,
@@ -353,8 +397,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const double* __restrict
                                                         const DevJob job) {
     const int lane = (int)(threadIdx.x & 63);
     DevWorld w = wc;
-    w.inv = g_inv;
-    w.geo = g_geo;
+    w.tab = g_tab;
     w.shade = g_shade;
 
     // per-lane frame stack (private memory: touched once per node, a few dozen bytes)
@@ -373,6 +416,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const double* __restrict
     const V3 light = {w.light_pos[0], w.light_pos[1], w.light_pos[2]};
     const V3 lint = {w.light_int[0], w.light_int[1], w.light_int[2]};
 
+#ifdef RTC_PROBE
+    const unsigned long long probe_t0 = wall_clock64();
+    unsigned long long probe_tx = 0;
+#endif
     for (;;) {
         // ---- hand new work to idle lanes ------------------------------------------------
         const unsigned long long idle = __ballot(out_index < 0);
@@ -382,6 +429,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const double* __restrict
             if (lane == (int)__ffsll((long long)idle) - 1) base = atomicAdd(g_counter, cnt);
             base = (uint32_t)__shfl((int)base, (int)__ffsll((long long)idle) - 1);
             if (base + cnt >= job.total || base + cnt < base) exhausted = true;
+#ifdef RTC_PROBE
+            if (exhausted && probe_tx == 0) probe_tx = wall_clock64();
+#endif
             if (out_index < 0) {
                 const uint32_t rank_in_wave = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 const uint32_t k = base + rank_in_wave;
@@ -426,14 +476,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const double* __restrict
             if (STATS) ++n_radiance;
             const int remaining = job.depth - sp;
             Sweep hit;
-            sweep_world<true, STATS>(g_inv, g_geo, w.n, ro, rd, hit, n_sphere_hits, n_plane_hits);
+            sweep_world<false, STATS>(g_tab, w.n, ro, rd, hit, n_sphere_hits, n_plane_hits);
 
             V3 ret = {0.0, 0.0, 0.0};  // Color.Black on a miss (calc.zig:650)
             bool descend = false;
             if (hit.idx >= 0) {
                 if (STATS) ++n_shaded;
                 const DevShade& sh = w.shade[hit.idx];
-                const double* __restrict__ oinv = w.inv + (size_t)hit.idx * 12;
+                const double* __restrict__ oinv = g_tab + (size_t)hit.idx * kRecDoubles;
 
                 // ---- calc.prepareComputations (calc.zig:247-306)
                 const V3 point = {ro.x + hit.t * rd.x, ro.y + hit.t * rd.y, ro.z + hit.t * rd.z};
@@ -470,8 +520,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const double* __restrict
                 const double distance = sqrt((lv.x * lv.x + lv.y * lv.y) + lv.z * lv.z);
                 const V3 lightv = {lv.x / distance, lv.y / distance, lv.z / distance};
                 Sweep sh_hit;
-                sweep_world<false, STATS>(g_inv, g_geo, w.n, over_point, lightv, sh_hit, n_sphere_hits, n_plane_hits);
-                const bool in_shadow = sh_hit.idx >= 0 && sh_hit.t < distance;
+                sh_hit.t = distance;
+                sweep_world<true, STATS>(g_tab, w.n, over_point, lightv, sh_hit, n_sphere_hits, n_plane_hits);
+                const bool in_shadow = sh_hit.idx >= 0;
 
                 // ---- calc.lighting (calc.zig:26-73) at over_point; lightv above is the same
                 // light.position.sub(position).normalize() the reference recomputes
@@ -614,6 +665,17 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const double* __restrict
         }
     }
 
+#ifdef RTC_PROBE
+    if (lane == 0) {
+        unsigned long long* pr = (unsigned long long*)((char*)g_counter + 64);
+        const unsigned wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (wid < 8192) {
+            pr[wid * 3 + 0] = probe_t0;
+            pr[wid * 3 + 1] = probe_tx;
+            pr[wid * 3 + 2] = wall_clock64();
+        }
+    }
+#endif
     if (STATS) {
         // one atomic per counter per wave
         uint32_t v[5] = {n_radiance, n_shadow, n_sphere_hits, n_plane_hits, n_shaded};
@@ -685,8 +747,8 @@ hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t 
     const uint64_t needed = ((uint64_t)job.total + kBlock - 1) / kBlock;
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.inv, world.geo, world.shade,
-                       job.rays, job.out, job.counter, (unsigned long long*)job.stats, world, job);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.tab, world.shade, job.rays,
+                       job.out, job.counter, (unsigned long long*)job.stats, world, job);
     return hipGetLastError();
 }
 

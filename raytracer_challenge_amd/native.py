@@ -11,7 +11,8 @@ import numpy as np
 
 from . import descs as D
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtc_hip.so")
+# RTC_HIP_LIB lets a developer point at another build of the same library (A/B timing).
+_LIB_PATH = os.environ.get("RTC_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librtc_hip.so")
 _lib = None
 
 

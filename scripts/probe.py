@@ -1,0 +1,27 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+from raytracer_challenge_amd import native, scenes
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+world, cam = {"c3": lambda: scenes.draw_world_scene(3840, 2160), "c2": lambda: scenes.draw_world_scene(1920, 1080),
+              "c4m": lambda: scenes.synthetic_scene(1920, 1080)}[wl]()
+cd = cam.desc()
+sc = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
+out = torch.empty(cd.hsize * cd.vsize * 3, dtype=torch.float64, device="cuda")
+for _ in range(2):
+    sc.render_device(cd, 5, out.data_ptr())
+torch.cuda.synchronize()
+L = native.lib()
+n = 4096
+buf = np.zeros((n, 3), dtype=np.uint64)
+L.rtc_debug_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+assert L.rtc_debug_probe(sc._h, buf.ctypes.data, n) == 0
+t0 = buf[:, 0].astype(np.int64); tx = buf[:, 1].astype(np.int64); te = buf[:, 2].astype(np.int64)
+ok = te > 0
+base = t0[ok].min()
+f = 1e-5  # 100 MHz ticks -> ms
+print("waves", ok.sum(), "start spread ms", (t0[ok].max() - base) * f)
+print("exhausted at ms: min %.3f med %.3f max %.3f" % tuple(np.percentile((tx[ok] - base) * f, [0, 50, 100])))
+print("end at ms: min %.3f p10 %.3f med %.3f p90 %.3f p99 %.3f max %.3f" % tuple(np.percentile((te[ok] - base) * f, [0, 10, 50, 90, 99, 100])))
+tail = (te[ok] - tx[ok]) * f
+print("per-wave (end - exhausted) ms: med %.3f p90 %.3f max %.3f" % tuple(np.percentile(tail, [50, 90, 100])))
