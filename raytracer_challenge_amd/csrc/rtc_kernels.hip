@@ -383,7 +383,25 @@ __device__ __forceinline__ V3 pattern_color(const DevShade& sh, const double* __
 //   transp   material.transparency (scales the refracted child, calc.zig:852)
 //   R        Schlick reflectance when flags & kSchlick (calc.zig:464-466)
 //   ray      the refracted ray, parked while the reflected subtree is traced
-enum : int { kHasRefract = 1, kSchlick = 2, kWaitRefract = 4 };
+// flags: kHasRefract — a refracted child exists; kWaitRefract — the reflected term is already
+// in acc and the frame waits for the refracted colour; kOutsourced — another lane of the wave
+// traces the refracted subtree (its lane id sits in bits 8..13).
+enum : int { kHasRefract = 1, kSchlick = 2, kWaitRefract = 4, kOutsourced = 8 };
+enum : int { kIdle = 0, kRun = 1, kHelperDone = 2 };
+constexpr int kChunk = 64;  // queue positions a wave draws at a time: one 8x8 block of pixels
+
+// Lane id of the n-th (0-based) set bit of mask; n < popcount(mask).
+__device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
+    int pos = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+        const int below = __popcll(mask & (((1ull << step) - 1ull) << pos));
+        const bool up = below <= n;
+        n -= up ? below : 0;
+        pos += up ? step : 0;
+    }
+    return pos;
+}
 
 // The read-only tables and the output are separate __restrict__ kernel arguments so that
 // the compiler can prove the wave-uniform table reads are never clobbered by the kernel's
@@ -396,6 +414,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                                                         unsigned long long* __restrict__ g_stats, const DevWorld wc,
                                                         const DevJob job) {
     const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     DevWorld w = wc;
     w.tab = g_tab;
     w.shade = g_shade;
@@ -408,10 +427,21 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 
     uint32_t n_radiance = 0, n_shadow = 0, n_sphere_hits = 0, n_plane_hits = 0, n_shaded = 0;
 
-    long long out_index = -1;  // < 0: lane holds no pixel
+    // Task state of the lane.  A task is a subtree of the reference's recursion: either a
+    // whole pixel (root) or, once the pixel queue is empty, a refracted subtree taken over
+    // from a busy lane of the same wave.
+    int mode = kIdle;
+    bool is_helper = false;    // the task is a taken-over subtree: its colour goes to `owner`, not to the canvas
+    bool waiting = false;      // top frame waits for a subtree another lane is tracing
+    int wait_lane = 0;         // ... that lane
+    int owner = 0;             // helper: the lane whose frame consumes this task's colour
+    int base_rem = 0;          // `remaining` (calc.zig:641) of the task's root ray
+    long long out_index = -1;  // root: where the pixel goes
     int sp = 0;
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
-    bool exhausted = false;  // wave-uniform
+    V3 res = {0, 0, 0};        // helper: finished colour, held until the owner has read it
+    bool exhausted = false;    // wave-uniform: the global pixel queue is empty
+    uint32_t loc_next = 0, loc_end = 0;  // wave-uniform: the chunk of queue positions the wave is dealing out
 
     const V3 light = {w.light_pos[0], w.light_pos[1], w.light_pos[2]};
     const V3 lint = {w.light_int[0], w.light_int[1], w.light_int[2]};
@@ -421,65 +451,162 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     unsigned long long probe_tx = 0;
 #endif
     for (;;) {
-        // ---- hand new work to idle lanes ------------------------------------------------
-        const unsigned long long idle = __ballot(out_index < 0);
-        if (idle != 0 && !exhausted) {
-            const uint32_t cnt = (uint32_t)__popcll(idle);
-            uint32_t base = 0;
-            if (lane == (int)__ffsll((long long)idle) - 1) base = atomicAdd(g_counter, cnt);
-            base = (uint32_t)__shfl((int)base, (int)__ffsll((long long)idle) - 1);
-            if (base + cnt >= job.total || base + cnt < base) exhausted = true;
+        // ---- hand new pixels to idle lanes ----------------------------------------------
+        // The wave draws chunks of kChunk consecutive queue positions (one 8x8 pixel block)
+        // from the global queue with one atomic, and deals them to its lanes as they fall
+        // idle.  A wave therefore works on one or two neighbouring blocks at a time, which
+        // keeps the rays of its lanes alike (same shapes hit, same shading branches).
+        for (int pass = 0; pass < 2; ++pass) {
+            const unsigned long long idle = __ballot(mode == kIdle);
+            if (idle == 0) break;
+            if (loc_next >= loc_end) {
+                if (exhausted) break;
+                const int leader = (int)__ffsll((long long)idle) - 1;
+                uint32_t base = 0;
+                const uint32_t chunk = (uint32_t)kChunk;
+                if (lane == leader) base = atomicAdd(g_counter, chunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, leader));
+                if (base + chunk >= job.total || base + chunk < base) exhausted = true;
 #ifdef RTC_PROBE
-            if (exhausted && probe_tx == 0) probe_tx = wall_clock64();
+                if (exhausted && probe_tx == 0) probe_tx = wall_clock64();
 #endif
-            if (out_index < 0) {
-                const uint32_t rank_in_wave = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                const uint32_t k = base + rank_in_wave;
-                if (k < job.total && base + rank_in_wave >= base) {
-                    if (FROM_RAYS) {
-                        const double* r = g_rays + (size_t)k * 6;
-                        ro = {r[0], r[1], r[2]};
-                        rd = {r[3], r[4], r[5]};
-                        out_index = (long long)k * 3;
-                        sp = 0;
-                    } else {
-                        // tile order: k -> (local tile, pixel in tile) -> canvas (x, y)
-                        const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
-                        const uint32_t lt = k / tile_px, within = k % tile_px;
-                        const uint32_t gt = lt * job.tile_ranks + job.tile_rank;
-                        const uint32_t px = (gt % job.tiles_x) * RTC_TILE_W + within % RTC_TILE_W;
-                        const uint32_t py = (gt / job.tiles_x) * RTC_TILE_H + within / RTC_TILE_W;
-                        if (gt < job.tiles_total && px < job.hsize && py < job.vsize) {
-                            // Camera.rayForPixel (camera.zig:48-72)
-                            const double x_offset = ((double)px + 0.5) * job.pixel_size;
-                            const double y_offset = ((double)py + 0.5) * job.pixel_size;
-                            const double world_x = job.half_width - x_offset;
-                            const double world_y = job.half_height - y_offset;
-                            const V3 pixel = xform_point(job.cam_inv, V3{world_x, world_y, -1.0});
-                            const V3 origin = xform_point(job.cam_inv, V3{0.0, 0.0, 0.0});
-                            ro = origin;
-                            rd = normalize3(V3{pixel.x - origin.x, pixel.y - origin.y, pixel.z - origin.z});
-                            out_index = job.tile_ranks == 1 ? ((long long)py * job.hsize + px) * 3 : (long long)k * 3;
-                            sp = 0;
-                        }
+                if (base >= job.total) break;
+                loc_next = base;
+                loc_end = base + chunk < job.total ? base + chunk : job.total;
+            }
+            const uint32_t avail = loc_end - loc_next;
+            const uint32_t rank_in_wave = (uint32_t)__popcll(idle & lanes_below);
+            if (mode == kIdle && rank_in_wave < avail) {
+                const uint32_t k = loc_next + rank_in_wave;
+                bool got_work = false;
+                if (FROM_RAYS) {
+                    const double* r = g_rays + (size_t)k * 6;
+                    ro = {r[0], r[1], r[2]};
+                    rd = {r[3], r[4], r[5]};
+                    out_index = (long long)k * 3;
+                    got_work = true;
+                } else {
+                    // queue position k -> (local tile, 8x8 block of the tile, pixel of the block)
+                    const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
+                    const uint32_t lt = k / tile_px, r = k % tile_px;
+                    const uint32_t tx = (r / 64) * 8 + (r % 8), ty = (r % 64) / 8;
+                    const uint32_t gt = lt * job.tile_ranks + job.tile_rank;
+                    const uint32_t px = (gt % job.tiles_x) * RTC_TILE_W + tx;
+                    const uint32_t py = (gt / job.tiles_x) * RTC_TILE_H + ty;
+                    if (gt < job.tiles_total && px < job.hsize && py < job.vsize) {
+                        // Camera.rayForPixel (camera.zig:48-72)
+                        const double x_offset = ((double)px + 0.5) * job.pixel_size;
+                        const double y_offset = ((double)py + 0.5) * job.pixel_size;
+                        const double world_x = job.half_width - x_offset;
+                        const double world_y = job.half_height - y_offset;
+                        const V3 pixel = xform_point(job.cam_inv, V3{world_x, world_y, -1.0});
+                        const V3 origin = xform_point(job.cam_inv, V3{0.0, 0.0, 0.0});
+                        ro = origin;
+                        rd = normalize3(V3{pixel.x - origin.x, pixel.y - origin.y, pixel.z - origin.z});
+                        // canvas index, or the slot of the rank's dense tile buffer (row-major in the tile)
+                        out_index = job.tile_ranks == 1 ? ((long long)py * job.hsize + px) * 3
+                                                        : ((long long)lt * tile_px + ty * RTC_TILE_W + tx) * 3;
+                        got_work = true;
                     }
+                }
+                if (got_work) {
+                    mode = kRun;
+                    is_helper = false;
+                    waiting = false;
+                    base_rem = job.depth;
+                    sp = 0;
+                }
+            }
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            loc_next += n_idle < avail ? n_idle : avail;
+        }
+        const bool drained = exhausted && loc_next >= loc_end;  // wave-uniform: no pixel left to start
+
+        bool have_ret = false;     // a finished subtree colour is in `ret`, to be unwound into the frames
+        V3 ret = {0.0, 0.0, 0.0};  // Color.Black on a miss (calc.zig:650)
+
+#ifndef RTC_NO_STEAL
+        // ---- queue empty: idle lanes take over parked refracted subtrees -------------------
+        // Only the order of evaluation changes: the subtree's colour is the same value whoever
+        // traces it, and the owner combines it at the same place in its post-order unwinding.
+        if (drained) {
+            // (1) owners waiting for a taken-over subtree read the helper's colour
+            const int hl = waiting ? wait_lane : lane;
+            const int h_done = __shfl((int)(mode == kHelperDone), hl);
+            const double hx = __shfl(res.x, hl), hy = __shfl(res.y, hl), hz = __shfl(res.z, hl);
+            const bool got = waiting && h_done != 0;
+            const int ack = __shfl(got ? hl : -1, owner);
+            if (mode == kHelperDone && ack == lane) mode = kIdle;
+            if (got) {
+                // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
+                const int f = sp - 1;
+                const double kt = f_transp[f];
+                V3 c = {kt * hx, kt * hy, kt * hz};
+                if (f_flags[f] & kSchlick) {
+                    const double T = 1.0 - f_R[f];
+                    c = {T * c.x, T * c.y, T * c.z};
+                }
+                ret = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
+                --sp;
+                waiting = false;
+                have_ret = true;
+            }
+            // (2) match parked refracted subtrees (shallowest first) with idle lanes
+            int offer_f = -1;
+            if (mode == kRun) {
+                for (int f = sp - 1; f >= 0; --f) {
+                    const int fl = f_flags[f];
+                    if ((fl & kHasRefract) && !(fl & (kWaitRefract | kOutsourced))) offer_f = f;
+                }
+            }
+            const unsigned long long offers = __ballot(offer_f >= 0);
+            const unsigned long long idles = __ballot(mode == kIdle);
+            if (offers != 0 && idles != 0) {
+                const int n_off = __popcll(offers), n_idle = __popcll(idles);
+                const int n_pairs = n_off < n_idle ? n_off : n_idle;
+                const int my_off = __popcll(offers & lanes_below), my_idle = __popcll(idles & lanes_below);
+                const bool give = offer_f >= 0 && my_off < n_pairs;
+                const bool take = mode == kIdle && my_idle < n_pairs;
+                int partner = lane;
+                if (give) partner = nth_set_bit(idles, my_off);
+                if (take) partner = nth_set_bit(offers, my_idle);
+                double p[6] = {0, 0, 0, 0, 0, 0};
+                if (give) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) p[q] = f_ray[offer_f][q];
+                    f_flags[offer_f] |= kOutsourced | (partner << 8);
+                }
+                const int p_rem = base_rem - offer_f - 1;
+                double t6[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) t6[q] = __shfl(p[q], partner);
+                const int t_rem = __shfl(p_rem, partner);
+                if (take) {
+                    ro = {t6[0], t6[1], t6[2]};
+                    rd = {t6[3], t6[4], t6[5]};
+                    base_rem = t_rem;
+                    sp = 0;
+                    mode = kRun;
+                    is_helper = true;
+                    waiting = false;
+                    owner = partner;
                 }
             }
         }
-        if (__ballot(out_index >= 0) == 0) {
-            if (exhausted) break;
+#endif
+        if (__ballot(mode != kIdle) == 0) {
+            if (drained) break;
             continue;
         }
 
-        if (out_index >= 0) {
+        if (mode == kRun && !waiting && !have_ret) {
             // ---- one tree node: calc.worldColorAt (calc.zig:641-652) ---------------------
             if (STATS) ++n_radiance;
-            const int remaining = job.depth - sp;
+            const int remaining = base_rem - sp;
             Sweep hit;
             sweep_world<false, STATS>(g_tab, w.n, ro, rd, hit, n_sphere_hits, n_plane_hits);
 
-            V3 ret = {0.0, 0.0, 0.0};  // Color.Black on a miss (calc.zig:650)
-            bool descend = false;
+            have_ret = true;
             if (hit.idx >= 0) {
                 if (STATS) ++n_shaded;
                 const DevShade& sh = w.shade[hit.idx];
@@ -606,7 +733,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                         rd = refr_dir;
                     }
                     ++sp;
-                    descend = true;
+                    have_ret = false;  // descend into the child in the next iteration
                 } else if (flags & kSchlick) {
                     // surface + Black.scale(R) + Black.scale(1 - R): a non-finite R must poison the colour
                     const double zr = R * 0.0, zt = (1.0 - R) * 0.0;
@@ -615,51 +742,62 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     ret = surface;  // surface + Black + Black
                 }
             }
+        }
 
-            // ---- unwind finished subtrees in the reference's post-order -------------------
-            if (!descend) {
-                while (sp > 0) {
-                    const int f = sp - 1;
-                    const int flags = f_flags[f];
-                    if (!(flags & kWaitRefract)) {
-                        // reflected child returned: color.scale(reflective) [.scale(reflectance)]
-                        const double kr = f_refl[f];
-                        V3 c = {kr * ret.x, kr * ret.y, kr * ret.z};
-                        if (flags & kSchlick) {
-                            const double R = f_R[f];
-                            c = {R * c.x, R * c.y, R * c.z};
-                        }
-                        const V3 acc = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
-                        if (flags & kHasRefract) {
-                            f_acc[f][0] = acc.x;
-                            f_acc[f][1] = acc.y;
-                            f_acc[f][2] = acc.z;
-                            f_flags[f] = flags | kWaitRefract;
+        // ---- unwind finished subtrees in the reference's post-order -----------------------
+        if (have_ret) {
+            bool settled = false;  // the lane descended into a child or waits for a helper
+            while (sp > 0) {
+                const int f = sp - 1;
+                const int flags = f_flags[f];
+                if (!(flags & kWaitRefract)) {
+                    // reflected child returned: color.scale(reflective) [.scale(reflectance)]
+                    const double kr = f_refl[f];
+                    V3 c = {kr * ret.x, kr * ret.y, kr * ret.z};
+                    if (flags & kSchlick) {
+                        const double R = f_R[f];
+                        c = {R * c.x, R * c.y, R * c.z};
+                    }
+                    const V3 acc = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
+                    if (flags & kHasRefract) {
+                        f_acc[f][0] = acc.x;
+                        f_acc[f][1] = acc.y;
+                        f_acc[f][2] = acc.z;
+                        f_flags[f] = flags | kWaitRefract;
+                        if (flags & kOutsourced) {
+                            waiting = true;
+                            wait_lane = (flags >> 8) & 63;
+                        } else {
                             ro = {f_ray[f][0], f_ray[f][1], f_ray[f][2]};
                             rd = {f_ray[f][3], f_ray[f][4], f_ray[f][5]};
-                            descend = true;
-                            break;
                         }
-                        ret = acc;  // + Black refracted term
-                        --sp;
-                    } else {
-                        // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
-                        const double kt = f_transp[f];
-                        V3 c = {kt * ret.x, kt * ret.y, kt * ret.z};
-                        if (flags & kSchlick) {
-                            const double T = 1.0 - f_R[f];
-                            c = {T * c.x, T * c.y, T * c.z};
-                        }
-                        ret = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
-                        --sp;
+                        settled = true;
+                        break;
                     }
+                    ret = acc;  // + Black refracted term
+                    --sp;
+                } else {
+                    // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
+                    const double kt = f_transp[f];
+                    V3 c = {kt * ret.x, kt * ret.y, kt * ret.z};
+                    if (flags & kSchlick) {
+                        const double T = 1.0 - f_R[f];
+                        c = {T * c.x, T * c.y, T * c.z};
+                    }
+                    ret = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
+                    --sp;
                 }
-                if (!descend) {
+            }
+            if (!settled) {
+                if (is_helper) {
+                    res = ret;
+                    mode = kHelperDone;
+                } else {
                     // canvas.set (canvas.zig:24-28)
                     g_out[out_index + 0] = ret.x;
                     g_out[out_index + 1] = ret.y;
                     g_out[out_index + 2] = ret.z;
-                    out_index = -1;
+                    mode = kIdle;
                 }
             }
         }
