@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    # developer switches to rehearse the N > 1 path on a box with one GPU: every rank uses GPU 0
+    # and the gather goes through host memory over gloo (never used for reported numbers)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="rank 0 checks the assembled canvas against a 1-rank render")
     args = ap.parse_args()
 
     import torch
@@ -130,12 +134,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     native.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     kind, hsize, vsize, desc = WORKLOADS[args.workload]
     if kind == "draw_world":
@@ -155,12 +164,23 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
 
+    def gather_and_assemble():
+        """RCCL gather of the per-rank tile buffers to rank 0, then scatter into the canvas."""
+        if args.rehearse_on_one_gpu:
+            host = local.cpu()
+            parts = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if rank == 0:
+                gathered.copy_(torch.stack(parts))
+        else:
+            dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+        if rank == 0:
+            native.deinterleave_device(cam, world_size, n_rank0, gathered.data_ptr(), canvas.data_ptr(), stream)
+
     def step():
         scene.render_device(cam, args.depth, local.data_ptr(), rank, world_size, stream)
         if world_size > 1:
-            dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                native.deinterleave_device(cam, world_size, n_rank0, gathered.data_ptr(), canvas.data_ptr(), stream)
+            gather_and_assemble()
 
     # deterministic work counters of this rank's share (outside the timed region)
     st = D.RtcStats()
@@ -193,9 +213,7 @@ def main():
         scene.render_device(cam, args.depth, local.data_ptr(), rank, world_size, stream)
         ev[i][1].record()
         if world_size > 1:
-            dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                native.deinterleave_device(cam, world_size, n_rank0, gathered.data_ptr(), canvas.data_ptr(), stream)
+            gather_and_assemble()
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
@@ -204,6 +222,14 @@ def main():
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max, kernel_ms_max = (float(v) for v in t.tolist())
+
+    if args.verify and world_size > 1 and rank == 0:
+        whole = torch.empty(hsize * vsize * 3, dtype=torch.float64, device=dev)
+        scene.render_device(cam, args.depth, whole.data_ptr(), 0, 1, stream)
+        torch.cuda.synchronize()
+        if not torch.equal(whole, canvas):
+            raise SystemExit("verify FAILED: assembled canvas differs from the 1-rank render")
+        print("verify ok: assembled canvas identical to the 1-rank render", file=sys.stderr)
 
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
