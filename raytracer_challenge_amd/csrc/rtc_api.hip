@@ -343,7 +343,14 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         double full[16];
         if (int rc = invert_affine(s.transform, full, "shape", i)) return rc;
         std::memcpy(&tab[i * kRec], full, 12 * sizeof(double));
-        const int64_t geo_word = s.geo;
+        // Tag bit 1: the entries of the inverse that the sweep would multiply in are exact
+        // zeros off the diagonal (sphere: the whole 3x3 is diagonal; plane: row 1 is (0,m,0)),
+        // so the sweep may skip those products without changing any value.
+        int64_t geo_word = s.geo;
+        const double* f = full;
+        const bool row1_axis = f[4] == 0.0 && f[6] == 0.0;
+        const bool diagonal = row1_axis && f[1] == 0.0 && f[2] == 0.0 && f[8] == 0.0 && f[9] == 0.0;
+        if (s.geo == RTC_GEO_SPHERE ? diagonal : row1_axis) geo_word |= 2;
         std::memcpy(&tab[i * kRec + 12], &geo_word, sizeof geo_word);
         rtc::DevShade& d = shade[i];
         std::memset(&d, 0, sizeof d);
@@ -415,7 +422,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     } while (0)
     SCENE_TRY(hipMalloc((void**)&sc->d_tab, tab.size() * sizeof(double)));
     SCENE_TRY(hipMalloc((void**)&sc->d_shade, n_alloc * sizeof(rtc::DevShade)));
-    SCENE_TRY(hipMalloc((void**)&sc->d_counter, 64 + 3 * 8 * 8192));  // queue head, stats, developer probe area
+    SCENE_TRY(hipMalloc((void**)&sc->d_counter, 64 + 11 * 8 * 8192));  // queue head, stats, developer probe area
     sc->d_stats = (uint64_t*)((char*)sc->d_counter + 8);
     SCENE_TRY(hipEventCreate(&sc->ev_start));
     SCENE_TRY(hipEventCreate(&sc->ev_stop));
@@ -556,7 +563,7 @@ int rtc_arith_probe(const double* a, const double* b, uint64_t n, double* out_di
 #ifdef RTC_PROBE
 int rtc_debug_probe(RtcScene* scene, uint64_t* out, uint64_t n_waves) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, (char*)scene->d_counter + 64, n_waves * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, (char*)scene->d_counter + 64, 11 * 8 * 8192, hipMemcpyDeviceToHost));
     return RTC_OK;
 }
 #endif

@@ -235,11 +235,12 @@ __device__ double zig_pow(double x, double y) {
 // container, so the result is unchanged.  The bounds assume t does not underflow to zero.
 struct Sweep {
     double t;         // nearest t >= 0 (valid when idx >= 0); for a shadow sweep: starts at the light distance
-    int idx;          // shape index of the hit, -1 = miss
-    bool exit_open;   // the hit is t2 of a sphere whose t1 < 0 (that sphere is an open container)
+    int idx;          // shape index of the hit, -1 = miss; bit 30 set: the hit is t2 of a sphere whose
+                      // t1 < 0 (that sphere is an open container)
     int top1, top2;   // innermost and second innermost open container, -1 = none
-    double top1_t, top2_t;
 };
+constexpr int kExitOpenBit = 1 << 30;
+constexpr int kAxisAlignedBit = 2;  // record tag bit: the matrix entries this shape's test would multiply by are exact zeros
 
 constexpr int kRecDoubles = 16;  // one shape record: 12 matrix entries, the geo tag, padding (128 B)
 constexpr double kOneMinus = 1.0 - 0x1p-40;
@@ -260,26 +261,27 @@ __device__ __forceinline__ ShapeRec load_rec(const double* __restrict__ tab, int
     return r;
 }
 
-__device__ __forceinline__ void push_container(Sweep& s, double t, int i) {
-    // ascending shape index: >= keeps the later shape on equal t, as the stable sort does
-    const bool first = s.top1 < 0 || t >= s.top1_t;
-    const bool second = !first && (s.top2 < 0 || t >= s.top2_t);
-    s.top2 = first ? s.top1 : (second ? i : s.top2);
-    s.top2_t = first ? s.top1_t : (second ? t : s.top2_t);
-    s.top1 = first ? i : s.top1;
-    s.top1_t = first ? t : s.top1_t;
-}
+// Per-lane list of the two innermost open containers, kept in LDS (24 B per lane).  It is
+// touched only when a lane actually meets a container (a plane behind the ray origin, or a
+// sphere the origin is inside), so it does not belong in registers: loop-carried registers
+// that are modified under a divergent branch cost a register copy per variable per shape.
+struct ContainerSlots {
+    double t[2][kBlock];
+    int i[2][kBlock];
+};
 
 // SHADOW: s.t holds the distance to the light on entry and only roots in [0, s.t) are
 // accepted (calc.zig:789: hit.t < distance); containers are not tracked.
 template <bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, int n, const V3& o, const V3& d, Sweep& s,
-                                            uint32_t& sphere_hits, uint32_t& plane_hits) {
+                                            ContainerSlots& cs, uint32_t& sphere_hits, uint32_t& plane_hits) {
+    const int tid = (int)threadIdx.x;
     s.idx = -1;
-    if (!SHADOW) s.t = 0.0;
-    s.exit_open = false;
-    s.top1 = s.top2 = -1;
-    s.top1_t = s.top2_t = 0.0;
+    if (!SHADOW) {
+        s.t = 0.0;
+        cs.i[0][tid] = -1;
+        cs.i[1][tid] = -1;
+    }
     ShapeRec cur = load_rec(tab, 0);
     for (int i = 0; i < n; ++i) {
         // Scalar loads return out of order, so the only wait is "all of them".  Consume the
@@ -288,11 +290,26 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, int 
         asm volatile("" ::"s"(cur.geo) : "memory");
         const ShapeRec nxt = load_rec(tab, i + 1);
         const double* m = cur.m;
+        // What this shape contributes, decided inside the branches below; the sweep state
+        // itself is only modified in straight-line code after them.
+        bool better = false;  // `cand` replaces the best hit
+        double cand = 0.0;
+        int cand_idx = i;
+        bool push = false;    // (push_t, i) is an open container
+        double push_t = 0.0;
         const bool have = SHADOW || s.idx >= 0;
-        if (cur.geo == RTC_GEO_SPHERE) {
+        if ((cur.geo & 1) == RTC_GEO_SPHERE) {
             // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
-            const V3 lo = xform_point(m, o);
-            const V3 ld = xform_dir(m, d);
+            V3 lo, ld;
+            if (cur.geo & kAxisAlignedBit) {
+                // the off-diagonal entries are exact zeros: their products are zeros and
+                // adding them changes no value, so they are not evaluated
+                lo = {m[0] * o.x + m[3], m[5] * o.y + m[7], m[10] * o.z + m[11]};
+                ld = {m[0] * d.x, m[5] * d.y, m[10] * d.z};
+            } else {
+                lo = xform_point(m, o);
+                ld = xform_dir(m, d);
+            }
             const double a = dot3(ld, ld);
             const double b = 2.0 * dot3(ld, lo);
             const double c = dot3(lo, lo) - 1.0;
@@ -313,38 +330,58 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, int 
                     const double t2 = (-b + sq) / den;
                     const bool in1 = t1 >= 0;
                     const bool in2 = !in1 && t2 >= 0;  // t2 >= t1 never beats t1 under strict <
-                    const double cand = in1 ? t1 : t2;
-                    const bool better = (in1 || in2) && (!have || cand < s.t);
-                    s.t = better ? cand : s.t;
-                    s.idx = better ? i : s.idx;
-                    s.exit_open = better ? in2 : s.exit_open;
-                    if (!SHADOW && in2) push_container(s, t1, i);
+                    cand = in1 ? t1 : t2;
+                    better = (in1 || in2) && (!have || cand < s.t);
+                    cand_idx = in2 ? (i | kExitOpenBit) : i;
+                    push = in2;
+                    push_t = t1;
                 }
             }
         } else {
             // Plane.localIntersect (shape.zig:55-70): only row 1 of the local ray is used
-            const double loy = ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7];
-            const double ldy = (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
+            const bool axis = (cur.geo & kAxisAlignedBit) != 0;  // m[4] and m[6] are exact zeros
+            const double ldy = axis ? m[5] * d.y : (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
             if (!(fabs(ldy) < kF64Eps)) {
                 if (STATS) ++plane_hits;
-                const bool behind = (loy < 0) == (ldy < 0) && loy != 0;
+                const double loy = axis ? m[5] * o.y + m[7] : ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7];
+                // sign of t = -loy/ldy from the sign of the product (a zero or underflowed
+                // product goes to the exact path)
+                const double p = -loy * ldy;
                 bool need;
-                if (behind)
-                    need = !SHADOW;
+                if (p < 0)
+                    need = !SHADOW;  // behind the origin: only a container
                 else
-                    need = !(have && fabs(loy) > (s.t * fabs(ldy)) * kOnePlus);
+                    need = !(have && p > (s.t * kOnePlus) * (ldy * ldy));  // |loy| > best*|ldy|*(1+2^-40)
                 if (need) {
                     const double t = -loy / ldy;
-                    const bool in = t >= 0;
-                    const bool better = in && (!have || t < s.t);
-                    s.t = better ? t : s.t;
-                    s.idx = better ? i : s.idx;
-                    s.exit_open = better ? false : s.exit_open;
-                    if (!SHADOW && t < 0) push_container(s, t, i);
+                    cand = t;
+                    better = t >= 0 && (!have || t < s.t);
+                    push = t < 0;
+                    push_t = t;
                 }
             }
         }
+        s.t = better ? cand : s.t;
+        s.idx = better ? cand_idx : s.idx;
+        if (!SHADOW && push) {
+            // ascending shape index: >= keeps the later shape on equal t, as the stable sort does
+            const int i1 = cs.i[0][tid], i2 = cs.i[1][tid];
+            const double c1 = cs.t[0][tid], c2 = cs.t[1][tid];
+            if (i1 < 0 || push_t >= c1) {
+                cs.i[1][tid] = i1;
+                cs.t[1][tid] = c1;
+                cs.i[0][tid] = i;
+                cs.t[0][tid] = push_t;
+            } else if (i2 < 0 || push_t >= c2) {
+                cs.i[1][tid] = i;
+                cs.t[1][tid] = push_t;
+            }
+        }
         cur = nxt;
+    }
+    if (!SHADOW) {
+        s.top1 = cs.i[0][tid];
+        s.top2 = cs.i[1][tid];
     }
 }
 
@@ -413,6 +450,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                                                         double* __restrict__ g_out, uint32_t* __restrict__ g_counter,
                                                         unsigned long long* __restrict__ g_stats, const DevWorld wc,
                                                         const DevJob job) {
+    __shared__ ContainerSlots containers;
     const int lane = (int)(threadIdx.x & 63);
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     DevWorld w = wc;
@@ -449,6 +487,18 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #ifdef RTC_PROBE
     const unsigned long long probe_t0 = wall_clock64();
     unsigned long long probe_tx = 0;
+    unsigned long long pc_refill = 0, pc_sweep1 = 0, pc_prep = 0, pc_sweep2 = 0, pc_shade = 0, pc_unwind = 0, pc_iters = 0;
+    unsigned long long pc_mark = clock64();
+#define RTC_STAMP(acc)                          \
+    do {                                        \
+        const unsigned long long _now = clock64(); \
+        acc += _now - pc_mark;                  \
+        pc_mark = _now;                         \
+    } while (0)
+#else
+#define RTC_STAMP(acc) \
+    do {               \
+    } while (0)
 #endif
     for (;;) {
         // ---- hand new pixels to idle lanes ----------------------------------------------
@@ -599,47 +649,48 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             continue;
         }
 
+        RTC_STAMP(pc_refill);
+#ifdef RTC_PROBE
+        ++pc_iters;
+#endif
         if (mode == kRun && !waiting && !have_ret) {
             // ---- one tree node: calc.worldColorAt (calc.zig:641-652) ---------------------
             if (STATS) ++n_radiance;
             const int remaining = base_rem - sp;
             Sweep hit;
-            sweep_world<false, STATS>(g_tab, w.n, ro, rd, hit, n_sphere_hits, n_plane_hits);
+            sweep_world<false, STATS>(g_tab, w.n, ro, rd, hit, containers, n_sphere_hits, n_plane_hits);
+            RTC_STAMP(pc_sweep1);
 
             have_ret = true;
             if (hit.idx >= 0) {
                 if (STATS) ++n_shaded;
+                const bool exit_open = (hit.idx & kExitOpenBit) != 0;
+                hit.idx &= ~kExitOpenBit;
                 const DevShade& sh = w.shade[hit.idx];
                 const double* __restrict__ oinv = g_tab + (size_t)hit.idx * kRecDoubles;
+                // gather what the normal needs in one batch (the loads overlap each other)
+                double M[12];
+#pragma unroll
+                for (int q = 0; q < 11; ++q) M[q] = oinv[q];
+                M[11] = oinv[11];
+                const int geo = sh.geo;
 
                 // ---- calc.prepareComputations (calc.zig:247-306)
                 const V3 point = {ro.x + hit.t * rd.x, ro.y + hit.t * rd.y, ro.z + hit.t * rd.z};
                 const V3 eyev = {-rd.x, -rd.y, -rd.z};
                 // Shape.normalAt (shape.zig:84-97)
                 V3 ln;
-                if (sh.geo == RTC_GEO_SPHERE) {
-                    ln = normalize3(xform_point(oinv, point));
+                if (geo == RTC_GEO_SPHERE) {
+                    ln = normalize3(xform_point(M, point));
                 } else {
                     ln = {0.0, 1.0, 0.0};
                 }
-                V3 normalv = normalize3(V3{(oinv[0] * ln.x + oinv[4] * ln.y) + oinv[8] * ln.z,
-                                           (oinv[1] * ln.x + oinv[5] * ln.y) + oinv[9] * ln.z,
-                                           (oinv[2] * ln.x + oinv[6] * ln.y) + oinv[10] * ln.z});
+                V3 normalv = normalize3(V3{(M[0] * ln.x + M[4] * ln.y) + M[8] * ln.z,
+                                           (M[1] * ln.x + M[5] * ln.y) + M[9] * ln.z,
+                                           (M[2] * ln.x + M[6] * ln.y) + M[10] * ln.z});
                 if (dot3(normalv, eyev) < 0) normalv = {-normalv.x, -normalv.y, -normalv.z};
-                const double two_dp = 2.0 * dot3(rd, normalv);  // Vec4.reflect, vector.zig:114-117
-                const V3 reflectv = {rd.x - two_dp * normalv.x, rd.y - two_dp * normalv.y, rd.z - two_dp * normalv.z};
                 const V3 offs = {kSurfaceEps * normalv.x, kSurfaceEps * normalv.y, kSurfaceEps * normalv.z};
                 const V3 over_point = {point.x + offs.x, point.y + offs.y, point.z + offs.z};
-                const V3 under_point = {point.x - offs.x, point.y - offs.y, point.z - offs.z};
-                // n1 / n2 from the open containers
-                const double n1 = hit.top1 < 0 ? 1.0 : w.shade[hit.top1].refractive_index;
-                double n2;
-                if (hit.exit_open) {
-                    const int rest = (hit.top1 == hit.idx) ? hit.top2 : hit.top1;
-                    n2 = rest < 0 ? 1.0 : w.shade[rest].refractive_index;
-                } else {
-                    n2 = sh.refractive_index;
-                }
 
                 // ---- calc.isShadowed (calc.zig:777-790) at over_point
                 if (STATS) ++n_shadow;
@@ -648,35 +699,53 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 const V3 lightv = {lv.x / distance, lv.y / distance, lv.z / distance};
                 Sweep sh_hit;
                 sh_hit.t = distance;
-                sweep_world<true, STATS>(g_tab, w.n, over_point, lightv, sh_hit, n_sphere_hits, n_plane_hits);
+                RTC_STAMP(pc_prep);
+                sweep_world<true, STATS>(g_tab, w.n, over_point, lightv, sh_hit, containers, n_sphere_hits, n_plane_hits);
+                RTC_STAMP(pc_sweep2);
                 const bool in_shadow = sh_hit.idx >= 0;
+
+                // material and refractive indices in one batch of gathers
+                const double m_ambient = sh.ambient, m_diffuse = sh.diffuse, m_specular = sh.specular,
+                             m_shininess = sh.shininess, m_reflective = sh.reflective,
+                             m_transparency = sh.transparency, m_ri = sh.refractive_index;
+                const int m_pattern = sh.pattern;
+                V3 color = {sh.color[0], sh.color[1], sh.color[2]};
+                // n1 / n2 from the open containers
+                const int rest = (hit.top1 == hit.idx) ? hit.top2 : hit.top1;
+                const double ri_top1 = hit.top1 < 0 ? 1.0 : w.shade[hit.top1].refractive_index;
+                const double ri_rest = rest < 0 ? 1.0 : w.shade[rest].refractive_index;
+                const double n1 = ri_top1;
+                const double n2 = exit_open ? ri_rest : m_ri;
+                // the rest of calc.prepareComputations (deferred past the shadow sweep: fewer live registers)
+                const double two_dp = 2.0 * dot3(rd, normalv);  // Vec4.reflect, vector.zig:114-117
+                const V3 reflectv = {rd.x - two_dp * normalv.x, rd.y - two_dp * normalv.y, rd.z - two_dp * normalv.z};
+                const V3 under_point = {point.x - offs.x, point.y - offs.y, point.z - offs.z};
 
                 // ---- calc.lighting (calc.zig:26-73) at over_point; lightv above is the same
                 // light.position.sub(position).normalize() the reference recomputes
-                V3 color = {sh.color[0], sh.color[1], sh.color[2]};
-                if (sh.pattern >= 0) color = pattern_color(sh, oinv, over_point);
+                if (m_pattern >= 0) color = pattern_color(sh, oinv, over_point);
                 const V3 eff = {color.x * lint.x, color.y * lint.y, color.z * lint.z};
-                V3 surface = {sh.ambient * eff.x, sh.ambient * eff.y, sh.ambient * eff.z};
+                V3 surface = {m_ambient * eff.x, m_ambient * eff.y, m_ambient * eff.z};
                 const double light_dot_normal = dot3(lightv, normalv);
                 if (light_dot_normal > 0.0 && !in_shadow) {
-                    const double kd = sh.diffuse * light_dot_normal;
+                    const double kd = m_diffuse * light_dot_normal;
                     surface = {surface.x + kd * eff.x, surface.y + kd * eff.y, surface.z + kd * eff.z};
                     const V3 nl = {-lightv.x, -lightv.y, -lightv.z};
                     const double two_ln = 2.0 * dot3(nl, normalv);
                     const V3 lr = {nl.x - two_ln * normalv.x, nl.y - two_ln * normalv.y, nl.z - two_ln * normalv.z};
                     const double reflect_dot_eye = dot3(lr, eyev);
                     if (reflect_dot_eye > 0.0) {
-                        const double ks = sh.specular * zig_pow(reflect_dot_eye, sh.shininess);
+                        const double ks = m_specular * zig_pow(reflect_dot_eye, m_shininess);
                         surface = {surface.x + ks * lint.x, surface.y + ks * lint.y, surface.z + ks * lint.z};
                     }
                 }
 
                 // ---- children: calc.reflectedColor (945-959), calc.refractedColor (828-853)
-                const bool has_reflect = remaining > 0 && !(fabs(sh.reflective) <= kF64Eps);
+                const bool has_reflect = remaining > 0 && !(fabs(m_reflective) <= kF64Eps);
                 bool has_refract = false;
                 V3 refr_dir = {0, 0, 0};
                 const double cos_i = dot3(eyev, normalv);
-                if (remaining > 0 && !(fabs(sh.transparency) <= kF64Eps)) {
+                if (remaining > 0 && !(fabs(m_transparency) <= kF64Eps)) {
                     const double n_ratio = n1 / n2;
                     const double sin2_t = n_ratio * n_ratio * (1 - cos_i * cos_i);
                     if (!(sin2_t > 1.0)) {
@@ -689,7 +758,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 }
                 int flags = has_refract ? kHasRefract : 0;
                 double R = 0.0;
-                if (sh.reflective > 0.0 && sh.transparency > 0.0) {
+                if (m_reflective > 0.0 && m_transparency > 0.0) {
                     // calc.schlick (calc.zig:1004-1026)
                     flags |= kSchlick;
                     double cosv = cos_i;
@@ -713,8 +782,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     f_acc[sp][0] = surface.x;
                     f_acc[sp][1] = surface.y;
                     f_acc[sp][2] = surface.z;
-                    f_refl[sp] = sh.reflective;
-                    f_transp[sp] = sh.transparency;
+                    f_refl[sp] = m_reflective;
+                    f_transp[sp] = m_transparency;
                     f_R[sp] = R;
                     if (has_reflect) {
                         f_ray[sp][0] = under_point.x;
@@ -744,48 +813,61 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             }
         }
 
+        RTC_STAMP(pc_shade);
         // ---- unwind finished subtrees in the reference's post-order -----------------------
         if (have_ret) {
             bool settled = false;  // the lane descended into a child or waits for a helper
-            while (sp > 0) {
-                const int f = sp - 1;
-                const int flags = f_flags[f];
-                if (!(flags & kWaitRefract)) {
-                    // reflected child returned: color.scale(reflective) [.scale(reflectance)]
-                    const double kr = f_refl[f];
-                    V3 c = {kr * ret.x, kr * ret.y, kr * ret.z};
-                    if (flags & kSchlick) {
-                        const double R = f_R[f];
-                        c = {R * c.x, R * c.y, R * c.z};
-                    }
-                    const V3 acc = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
-                    if (flags & kHasRefract) {
-                        f_acc[f][0] = acc.x;
-                        f_acc[f][1] = acc.y;
-                        f_acc[f][2] = acc.z;
-                        f_flags[f] = flags | kWaitRefract;
-                        if (flags & kOutsourced) {
-                            waiting = true;
-                            wait_lane = (flags >> 8) & 63;
-                        } else {
-                            ro = {f_ray[f][0], f_ray[f][1], f_ray[f][2]};
-                            rd = {f_ray[f][3], f_ray[f][4], f_ray[f][5]};
+            if (sp > 0) {
+                // The fields of the top frame are loaded in one batch, and those of the frame
+                // below are requested before the top one is combined, so that popping several
+                // frames costs about one memory latency instead of one per field per frame.
+                int f = sp - 1;
+                int flags = f_flags[f];
+                double kr = f_refl[f], kt = f_transp[f], fR = f_R[f];
+                V3 acc0 = {f_acc[f][0], f_acc[f][1], f_acc[f][2]};
+                for (;;) {
+                    const int fn = f > 0 ? f - 1 : 0;
+                    const int n_flags = f_flags[fn];
+                    const double n_kr = f_refl[fn], n_kt = f_transp[fn], n_R = f_R[fn];
+                    const V3 n_acc = {f_acc[fn][0], f_acc[fn][1], f_acc[fn][2]};
+                    if (!(flags & kWaitRefract)) {
+                        // reflected child returned: color.scale(reflective) [.scale(reflectance)]
+                        V3 c = {kr * ret.x, kr * ret.y, kr * ret.z};
+                        if (flags & kSchlick) c = {fR * c.x, fR * c.y, fR * c.z};
+                        const V3 acc = {acc0.x + c.x, acc0.y + c.y, acc0.z + c.z};
+                        if (flags & kHasRefract) {
+                            f_acc[f][0] = acc.x;
+                            f_acc[f][1] = acc.y;
+                            f_acc[f][2] = acc.z;
+                            f_flags[f] = flags | kWaitRefract;
+                            if (flags & kOutsourced) {
+                                waiting = true;
+                                wait_lane = (flags >> 8) & 63;
+                            } else {
+                                ro = {f_ray[f][0], f_ray[f][1], f_ray[f][2]};
+                                rd = {f_ray[f][3], f_ray[f][4], f_ray[f][5]};
+                            }
+                            settled = true;
+                            break;
                         }
-                        settled = true;
-                        break;
+                        ret = acc;  // + Black refracted term
+                    } else {
+                        // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
+                        V3 c = {kt * ret.x, kt * ret.y, kt * ret.z};
+                        if (flags & kSchlick) {
+                            const double T = 1.0 - fR;
+                            c = {T * c.x, T * c.y, T * c.z};
+                        }
+                        ret = {acc0.x + c.x, acc0.y + c.y, acc0.z + c.z};
                     }
-                    ret = acc;  // + Black refracted term
                     --sp;
-                } else {
-                    // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
-                    const double kt = f_transp[f];
-                    V3 c = {kt * ret.x, kt * ret.y, kt * ret.z};
-                    if (flags & kSchlick) {
-                        const double T = 1.0 - f_R[f];
-                        c = {T * c.x, T * c.y, T * c.z};
-                    }
-                    ret = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
-                    --sp;
+                    if (sp == 0) break;
+                    f = fn;
+                    flags = n_flags;
+                    kr = n_kr;
+                    kt = n_kt;
+                    fR = n_R;
+                    acc0 = n_acc;
                 }
             }
             if (!settled) {
@@ -801,6 +883,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 }
             }
         }
+        RTC_STAMP(pc_unwind);
     }
 
 #ifdef RTC_PROBE
@@ -811,6 +894,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             pr[wid * 3 + 0] = probe_t0;
             pr[wid * 3 + 1] = probe_tx;
             pr[wid * 3 + 2] = wall_clock64();
+            unsigned long long* pc = pr + 3 * 8192 + wid * 8;
+            pc[0] = pc_refill; pc[1] = pc_sweep1; pc[2] = pc_prep; pc[3] = pc_sweep2; pc[4] = pc_shade; pc[5] = pc_unwind; pc[6] = pc_iters;
         }
     }
 #endif

@@ -13,9 +13,10 @@ for _ in range(2):
 torch.cuda.synchronize()
 L = native.lib()
 n = 4096
-buf = np.zeros((n, 3), dtype=np.uint64)
+raw = np.zeros(11 * 8192, dtype=np.uint64)
+buf = raw[: 3 * 8192].reshape(8192, 3)[:n]
 L.rtc_debug_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
-assert L.rtc_debug_probe(sc._h, buf.ctypes.data, n) == 0
+assert L.rtc_debug_probe(sc._h, raw.ctypes.data, n) == 0
 t0 = buf[:, 0].astype(np.int64); tx = buf[:, 1].astype(np.int64); te = buf[:, 2].astype(np.int64)
 ok = te > 0
 base = t0[ok].min()
@@ -25,3 +26,11 @@ print("exhausted at ms: min %.3f med %.3f max %.3f" % tuple(np.percentile((tx[ok
 print("end at ms: min %.3f p10 %.3f med %.3f p90 %.3f p99 %.3f max %.3f" % tuple(np.percentile((te[ok] - base) * f, [0, 10, 50, 90, 99, 100])))
 tail = (te[ok] - tx[ok]) * f
 print("per-wave (end - exhausted) ms: med %.3f p90 %.3f max %.3f" % tuple(np.percentile(tail, [50, 90, 100])))
+
+pc = raw[3 * 8192:].reshape(8192, 8)[:n][ok].astype(np.float64)
+names = ["refill+steal", "sweep1", "prep", "sweep2", "shade", "unwind"]
+tot = pc[:, :6].sum()
+iters = pc[:, 6].sum()
+print("wave-iterations", int(iters), " cycles per wave-iteration %.0f" % (tot / iters))
+for k, nme in enumerate(names):
+    print("  %-13s %5.1f%%  %8.0f cycles/iter" % (nme, 100 * pc[:, k].sum() / tot, pc[:, k].sum() / iters))
