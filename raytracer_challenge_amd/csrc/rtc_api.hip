@@ -176,6 +176,8 @@ struct RtcScene {
     uint64_t n = 0;
     uint64_t n_spheres = 0, n_planes = 0;
     double* d_tab = nullptr;
+    int32_t* d_order = nullptr;
+    int32_t group[5] = {0, 0, 0, 0, 0};
     rtc::DevShade* d_shade = nullptr;
     uint32_t* d_counter = nullptr;  // work-queue head (4 B) followed by 5 x uint64 stats
     uint64_t* d_stats = nullptr;
@@ -189,6 +191,7 @@ namespace {
 void free_scene(RtcScene* s) {
     if (!s) return;
     if (s->d_tab) (void)hipFree(s->d_tab);
+    if (s->d_order) (void)hipFree(s->d_order);
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
@@ -199,6 +202,8 @@ void free_scene(RtcScene* s) {
 rtc::DevWorld dev_world(const RtcScene* s) {
     rtc::DevWorld w{};
     w.tab = s->d_tab;
+    w.order = s->d_order;
+    std::memcpy(w.group, s->group, sizeof w.group);
     w.shade = s->d_shade;
     w.n = (int32_t)s->n;
     for (int i = 0; i < 3; ++i) {
@@ -328,7 +333,8 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         return fail(RTC_ERR_INVALID_ARGUMENT, "light.position must be a point (w == 1)");
 
     constexpr size_t kRec = 16;  // doubles per sweep-table record, see DevWorld
-    std::vector<double> tab((n_shapes + 1) * kRec, 0.0);
+    std::vector<double> inv12(n_shapes * 12);
+    std::vector<int> group_of(n_shapes);
     std::vector<rtc::DevShade> shade(n_shapes);
     uint64_t n_spheres = 0, n_planes = 0;
     std::unordered_map<uint64_t, std::vector<uint64_t>> buckets;
@@ -342,16 +348,14 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         (s.geo == RTC_GEO_SPHERE ? n_spheres : n_planes)++;
         double full[16];
         if (int rc = invert_affine(s.transform, full, "shape", i)) return rc;
-        std::memcpy(&tab[i * kRec], full, 12 * sizeof(double));
-        // Tag bit 1: the entries of the inverse that the sweep would multiply in are exact
-        // zeros off the diagonal (sphere: the whole 3x3 is diagonal; plane: row 1 is (0,m,0)),
-        // so the sweep may skip those products without changing any value.
-        int64_t geo_word = s.geo;
+        std::memcpy(&inv12[i * 12], full, 12 * sizeof(double));
+        // Group by what the sweep can skip: where the entries of the inverse that a shape's
+        // test multiplies in are exact zeros (sphere: the 3x3 is diagonal; plane: row 1 is
+        // (0,m,0)), the products are zeros that change no value and are not evaluated.
         const double* f = full;
         const bool row1_axis = f[4] == 0.0 && f[6] == 0.0;
         const bool diagonal = row1_axis && f[1] == 0.0 && f[2] == 0.0 && f[8] == 0.0 && f[9] == 0.0;
-        if (s.geo == RTC_GEO_SPHERE ? diagonal : row1_axis) geo_word |= 2;
-        std::memcpy(&tab[i * kRec + 12], &geo_word, sizeof geo_word);
+        group_of[i] = s.geo == RTC_GEO_SPHERE ? (diagonal ? 0 : 1) : (row1_axis ? 2 : 3);
         rtc::DevShade& d = shade[i];
         std::memset(&d, 0, sizeof d);
         const RtcMaterialDesc& m = s.material;
@@ -397,6 +401,28 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         }
     }
 
+    // table order: the four groups one after the other, each in list order
+    std::vector<double> tab((n_shapes + 2) * kRec, 0.0);
+    std::vector<int32_t> order(n_shapes ? n_shapes : 1, 0);
+    std::vector<rtc::DevShade> shade_tab(n_shapes);
+    int32_t group[5] = {0, 0, 0, 0, 0};
+    {
+        size_t pos = 0;
+        for (int g = 0; g < 4; ++g) {
+            group[g] = (int32_t)pos;
+            for (uint64_t i = 0; i < n_shapes; ++i) {
+                if (group_of[i] != g) continue;
+                std::memcpy(&tab[pos * kRec], &inv12[i * 12], 12 * sizeof(double));
+                const int64_t order_word = (int64_t)i;
+                std::memcpy(&tab[pos * kRec + 12], &order_word, sizeof order_word);
+                order[pos] = (int32_t)i;
+                shade_tab[pos] = shade[i];
+                ++pos;
+            }
+        }
+        group[4] = (int32_t)pos;
+    }
+
     RtcScene* sc = new (std::nothrow) RtcScene();
     if (!sc) return fail(RTC_ERR_OUT_OF_MEMORY, "host allocation failed");
     hipError_t e = hipGetDevice(&sc->device);
@@ -426,9 +452,12 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     sc->d_stats = (uint64_t*)((char*)sc->d_counter + 8);
     SCENE_TRY(hipEventCreate(&sc->ev_start));
     SCENE_TRY(hipEventCreate(&sc->ev_stop));
+    SCENE_TRY(hipMalloc((void**)&sc->d_order, order.size() * sizeof(int32_t)));
     SCENE_TRY(hipMemcpy(sc->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    SCENE_TRY(hipMemcpy(sc->d_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (n_shapes)
-        SCENE_TRY(hipMemcpy(sc->d_shade, shade.data(), n_shapes * sizeof(rtc::DevShade), hipMemcpyHostToDevice));
+        SCENE_TRY(hipMemcpy(sc->d_shade, shade_tab.data(), n_shapes * sizeof(rtc::DevShade), hipMemcpyHostToDevice));
+    std::memcpy(sc->group, group, sizeof group);
 #undef SCENE_TRY
     *out_scene = sc;
     return RTC_OK;

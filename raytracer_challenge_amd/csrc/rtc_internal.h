@@ -29,15 +29,21 @@ struct DevShade {
 // Device-side view of an uploaded world.
 //
 // Layout in HBM (all allocated once per scene, read-only while rendering):
-//   tab   : (n+1) x 16 doubles, one 128-byte record per shape in list order: [0..11] rows
-//           0..2 of inverse(shape.transform), row-major 3x4; [12] the RTC_GEO_* tag (as the
-//           low bits of the word); [13..15] padding.  The sweep reads it with wave-uniform
-//           addresses, one record ahead, so record n exists as padding.
-//   shade : n x DevShade   — gathered per lane at a hit.
+// The shapes are stored in "table order": four groups (spheres whose inverse is diagonal,
+// other spheres, planes whose inverse row 1 is (0,m,0,t), other planes), each group in the
+// reference's list order.  group[g]..group[g+1] are the table positions of group g.
+//   tab   : (n+2) x 16 doubles, one 128-byte record per shape: [0..11] rows 0..2 of
+//           inverse(shape.transform), row-major 3x4; [12] the shape's index in the reference's
+//           list (an integer in the low bits of the word); [13..15] padding.  The sweep reads
+//           it with wave-uniform addresses, up to two records ahead, hence two padding records.
+//   shade : n x DevShade, table order — gathered per lane at a hit.
+//   order : n x int32, table position -> list index (tie-breaks between equal t).
 struct DevWorld {
     const double* tab;
     const DevShade* shade;
+    const int32_t* order;
     int32_t n;
+    int32_t group[5];
     double light_pos[3];
     double light_int[3];
 };

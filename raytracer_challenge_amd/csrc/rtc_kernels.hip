@@ -235,29 +235,28 @@ __device__ double zig_pow(double x, double y) {
 // container, so the result is unchanged.  The bounds assume t does not underflow to zero.
 struct Sweep {
     double t;         // nearest t >= 0 (valid when idx >= 0); for a shadow sweep: starts at the light distance
-    int idx;          // shape index of the hit, -1 = miss; bit 30 set: the hit is t2 of a sphere whose
-                      // t1 < 0 (that sphere is an open container)
-    int top1, top2;   // innermost and second innermost open container, -1 = none
+    int idx;          // table position of the hit shape, -1 = miss; bit 30 set: the hit is t2 of a sphere
+                      // whose t1 < 0 (that sphere is an open container)
+    int top1, top2;   // innermost and second innermost open container (table positions), -1 = none
 };
 constexpr int kExitOpenBit = 1 << 30;
-constexpr int kAxisAlignedBit = 2;  // record tag bit: the matrix entries this shape's test would multiply by are exact zeros
 
-constexpr int kRecDoubles = 16;  // one shape record: 12 matrix entries, the geo tag, padding (128 B)
+constexpr int kRecDoubles = 16;  // one shape record: 12 matrix entries, the list index, padding (128 B)
 constexpr double kOneMinus = 1.0 - 0x1p-40;
 constexpr double kOnePlus = 1.0 + 0x1p-40;
 
 struct ShapeRec {
     double m[12];
-    long long geo;
+    long long order;  // index of the shape in the reference's list (world.objects)
 };
-// Wave-uniform read of record i (scalar loads); record n is padding so that reading one
-// record ahead is always in bounds.
+// Wave-uniform read of the record at table position i (scalar loads); the table ends with
+// padding records so that reading ahead is always in bounds.
 __device__ __forceinline__ ShapeRec load_rec(const double* __restrict__ tab, int i) {
     ShapeRec r;
     const double* __restrict__ p = tab + (size_t)i * kRecDoubles;
 #pragma unroll
     for (int k = 0; k < 12; ++k) r.m[k] = p[k];
-    r.geo = __double_as_longlong(p[12]);
+    r.order = __double_as_longlong(p[12]);
     return r;
 }
 
@@ -270,11 +269,144 @@ struct ContainerSlots {
     int i[2][kBlock];
 };
 
+// The table holds the shapes in four groups, each in list order, so that each group is
+// swept by a loop specialised for it: no per-shape dispatch, and the zero entries of
+// axis-aligned inverses are never multiplied.
+enum : int { kSphereAxis = 0, kSphereGeneral = 1, kPlaneAxis = 2, kPlaneGeneral = 3 };
+
+// One shape against one ray.  The reference's list order decides ties (stable sort by t,
+// ray.zig:75-92): among equal t the shape earlier in the list is the hit, and the one later
+// in the list is the inner container.  The groups are not visited in list order, so ties
+// are resolved explicitly with the list indices (`order`), in the rare branch where two t
+// are equal.
+template <int KIND, bool SHADOW, bool STATS>
+__device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const int* __restrict__ order_of,
+                                            const V3& o, const V3& d, Sweep& s, ContainerSlots& cs,
+                                            uint32_t& sphere_hits, uint32_t& plane_hits) {
+    const double* m = rec.m;
+    const int tid = (int)threadIdx.x;
+    // What this shape contributes, decided inside the branches below; the sweep state itself
+    // is only modified in straight-line code after them.
+    bool better = false;  // `cand` replaces the best hit
+    double cand = 0.0;
+    int cand_idx = pos;
+    bool push = false;    // (push_t, pos) is an open container
+    double push_t = 0.0;
+    const bool have = SHADOW || s.idx >= 0;
+    if (KIND == kSphereAxis || KIND == kSphereGeneral) {
+        // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
+        V3 lo, ld;
+        if (KIND == kSphereAxis) {
+            // the off-diagonal entries are exact zeros: their products are zeros and adding
+            // them changes no value, so they are not evaluated
+            lo = {m[0] * o.x + m[3], m[5] * o.y + m[7], m[10] * o.z + m[11]};
+            ld = {m[0] * d.x, m[5] * d.y, m[10] * d.z};
+        } else {
+            lo = xform_point(m, o);
+            ld = xform_dir(m, d);
+        }
+        const double a = dot3(ld, ld);
+        const double b = 2.0 * dot3(ld, lo);
+        const double c = dot3(lo, lo) - 1.0;
+        const double bb = b * b;
+        const double disc = bb - 4.0 * a * c;
+        if (!(disc < 0)) {
+            if (STATS) ++sphere_hits;
+            const double den = 2.0 * a;
+            bool need = !(b > 0 && disc < bb * kOneMinus);
+            if (have) {
+                const double bd = s.t * den;
+                const double L = (-b - bd) - 0x1p-40 * (fabs(b) + bd);
+                need = need && !(L > 0 && L * L > disc * kOnePlus);
+            }
+            if (need) {
+                const double sq = sqrt(disc);
+                const double t1 = (-b - sq) / den;
+                const double t2 = (-b + sq) / den;
+                const bool in1 = t1 >= 0;
+                const bool in2 = !in1 && t2 >= 0;  // t2 >= t1 never beats t1 under strict <
+                cand = in1 ? t1 : t2;
+                better = (in1 || in2) && (!have || cand < s.t);
+                if (!SHADOW && (in1 || in2) && s.idx >= 0 && cand == s.t)
+                    better = (int)rec.order < order_of[s.idx & ~kExitOpenBit];
+                cand_idx = in2 ? (pos | kExitOpenBit) : pos;
+                push = in2;
+                push_t = t1;
+            }
+        }
+    } else {
+        // Plane.localIntersect (shape.zig:55-70): only row 1 of the local ray is used
+        double loy, ldy;
+        if (KIND == kPlaneAxis) {  // m[4] and m[6] are exact zeros
+            ldy = m[5] * d.y;
+            loy = m[5] * o.y + m[7];
+        } else {
+            ldy = (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
+            loy = ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7];
+        }
+        const bool hits = !(fabs(ldy) < kF64Eps);
+        if (STATS && hits) ++plane_hits;
+        // sign of t = -loy/ldy from the sign of the product (a zero or underflowed product
+        // goes to the exact path); beyond the best hit when |loy| > best*|ldy|*(1+2^-40)
+        const double p = -loy * ldy;
+        const double lim = (s.t * kOnePlus) * (ldy * ldy);
+        const bool need = hits && (p < 0 ? !SHADOW : !(have && p > lim));
+        if (need) {
+            const double t = -loy / ldy;
+            cand = t;
+            better = t >= 0 && (!have || t < s.t);
+            if (!SHADOW && t >= 0 && s.idx >= 0 && t == s.t)
+                better = (int)rec.order < order_of[s.idx & ~kExitOpenBit];
+            push = t < 0;
+            push_t = t;
+        }
+    }
+    s.t = better ? cand : s.t;
+    s.idx = better ? cand_idx : s.idx;
+    if (!SHADOW && push) {
+        // the container later in the sorted list (larger t; on equal t later in the list) is the inner one
+        const int i1 = cs.i[0][tid], i2 = cs.i[1][tid];
+        const double c1 = cs.t[0][tid], c2 = cs.t[1][tid];
+        const int my_order = (int)rec.order;
+        const bool after1 = i1 < 0 || push_t > c1 || (push_t == c1 && my_order > order_of[i1]);
+        if (after1) {
+            cs.i[1][tid] = i1;
+            cs.t[1][tid] = c1;
+            cs.i[0][tid] = pos;
+            cs.t[0][tid] = push_t;
+        } else if (i2 < 0 || push_t > c2 || (push_t == c2 && my_order > order_of[i2])) {
+            cs.i[1][tid] = pos;
+            cs.t[1][tid] = push_t;
+        }
+    }
+}
+
+// Sweep of one group, two shapes per loop trip.  Scalar loads return out of order, so the
+// only wait is "all of them": each record is consumed first (that wait covers only its own
+// loads), then the record after the next is requested and stays in flight during the
+// arithmetic.  The two record buffers alternate, so no register copies are needed.
+template <int KIND, bool SHADOW, bool STATS>
+__device__ __forceinline__ void sweep_group(const double* __restrict__ tab, const int* __restrict__ order_of, int begin,
+                                            int end, const V3& o, const V3& d, Sweep& s, ContainerSlots& cs,
+                                            uint32_t& sphere_hits, uint32_t& plane_hits) {
+    if (begin >= end) return;
+    ShapeRec A = load_rec(tab, begin);
+    for (int i = begin; i < end; i += 2) {
+        asm volatile("" ::"s"(A.order) : "memory");
+        const ShapeRec B = load_rec(tab, i + 1);
+        sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, s, cs, sphere_hits, plane_hits);
+        asm volatile("" ::"s"(B.order) : "memory");
+        A = load_rec(tab, i + 2);
+        if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, s, cs, sphere_hits, plane_hits);
+    }
+}
+
 // SHADOW: s.t holds the distance to the light on entry and only roots in [0, s.t) are
 // accepted (calc.zig:789: hit.t < distance); containers are not tracked.
 template <bool SHADOW, bool STATS>
-__device__ __forceinline__ void sweep_world(const double* __restrict__ tab, int n, const V3& o, const V3& d, Sweep& s,
-                                            ContainerSlots& cs, uint32_t& sphere_hits, uint32_t& plane_hits) {
+__device__ __forceinline__ void sweep_world(const double* __restrict__ tab, const int* __restrict__ order_of,
+                                            const DevWorld& w, const V3& o, const V3& d, Sweep& s, ContainerSlots& cs,
+                                            uint32_t& sphere_hits, uint32_t& plane_hits) {
     const int tid = (int)threadIdx.x;
     s.idx = -1;
     if (!SHADOW) {
@@ -282,103 +414,10 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, int 
         cs.i[0][tid] = -1;
         cs.i[1][tid] = -1;
     }
-    ShapeRec cur = load_rec(tab, 0);
-    for (int i = 0; i < n; ++i) {
-        // Scalar loads return out of order, so the only wait is "all of them".  Consume the
-        // current record first (that wait covers only its own loads), then request the next
-        // one, which stays in flight during this shape's arithmetic.
-        asm volatile("" ::"s"(cur.geo) : "memory");
-        const ShapeRec nxt = load_rec(tab, i + 1);
-        const double* m = cur.m;
-        // What this shape contributes, decided inside the branches below; the sweep state
-        // itself is only modified in straight-line code after them.
-        bool better = false;  // `cand` replaces the best hit
-        double cand = 0.0;
-        int cand_idx = i;
-        bool push = false;    // (push_t, i) is an open container
-        double push_t = 0.0;
-        const bool have = SHADOW || s.idx >= 0;
-        if ((cur.geo & 1) == RTC_GEO_SPHERE) {
-            // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
-            V3 lo, ld;
-            if (cur.geo & kAxisAlignedBit) {
-                // the off-diagonal entries are exact zeros: their products are zeros and
-                // adding them changes no value, so they are not evaluated
-                lo = {m[0] * o.x + m[3], m[5] * o.y + m[7], m[10] * o.z + m[11]};
-                ld = {m[0] * d.x, m[5] * d.y, m[10] * d.z};
-            } else {
-                lo = xform_point(m, o);
-                ld = xform_dir(m, d);
-            }
-            const double a = dot3(ld, ld);
-            const double b = 2.0 * dot3(ld, lo);
-            const double c = dot3(lo, lo) - 1.0;
-            const double bb = b * b;
-            const double disc = bb - 4.0 * a * c;
-            if (!(disc < 0)) {
-                if (STATS) ++sphere_hits;
-                const double den = 2.0 * a;
-                bool need = !(b > 0 && disc < bb * kOneMinus);
-                if (have) {
-                    const double bd = s.t * den;
-                    const double L = (-b - bd) - 0x1p-40 * (fabs(b) + bd);
-                    need = need && !(L > 0 && L * L > disc * kOnePlus);
-                }
-                if (need) {
-                    const double sq = sqrt(disc);
-                    const double t1 = (-b - sq) / den;
-                    const double t2 = (-b + sq) / den;
-                    const bool in1 = t1 >= 0;
-                    const bool in2 = !in1 && t2 >= 0;  // t2 >= t1 never beats t1 under strict <
-                    cand = in1 ? t1 : t2;
-                    better = (in1 || in2) && (!have || cand < s.t);
-                    cand_idx = in2 ? (i | kExitOpenBit) : i;
-                    push = in2;
-                    push_t = t1;
-                }
-            }
-        } else {
-            // Plane.localIntersect (shape.zig:55-70): only row 1 of the local ray is used
-            const bool axis = (cur.geo & kAxisAlignedBit) != 0;  // m[4] and m[6] are exact zeros
-            const double ldy = axis ? m[5] * d.y : (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
-            if (!(fabs(ldy) < kF64Eps)) {
-                if (STATS) ++plane_hits;
-                const double loy = axis ? m[5] * o.y + m[7] : ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7];
-                // sign of t = -loy/ldy from the sign of the product (a zero or underflowed
-                // product goes to the exact path)
-                const double p = -loy * ldy;
-                bool need;
-                if (p < 0)
-                    need = !SHADOW;  // behind the origin: only a container
-                else
-                    need = !(have && p > (s.t * kOnePlus) * (ldy * ldy));  // |loy| > best*|ldy|*(1+2^-40)
-                if (need) {
-                    const double t = -loy / ldy;
-                    cand = t;
-                    better = t >= 0 && (!have || t < s.t);
-                    push = t < 0;
-                    push_t = t;
-                }
-            }
-        }
-        s.t = better ? cand : s.t;
-        s.idx = better ? cand_idx : s.idx;
-        if (!SHADOW && push) {
-            // ascending shape index: >= keeps the later shape on equal t, as the stable sort does
-            const int i1 = cs.i[0][tid], i2 = cs.i[1][tid];
-            const double c1 = cs.t[0][tid], c2 = cs.t[1][tid];
-            if (i1 < 0 || push_t >= c1) {
-                cs.i[1][tid] = i1;
-                cs.t[1][tid] = c1;
-                cs.i[0][tid] = i;
-                cs.t[0][tid] = push_t;
-            } else if (i2 < 0 || push_t >= c2) {
-                cs.i[1][tid] = i;
-                cs.t[1][tid] = push_t;
-            }
-        }
-        cur = nxt;
-    }
+    sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, s, cs, sphere_hits, plane_hits);
+    sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, s, cs, sphere_hits, plane_hits);
+    sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, s, cs, sphere_hits, plane_hits);
+    sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, s, cs, sphere_hits, plane_hits);
     if (!SHADOW) {
         s.top1 = cs.i[0][tid];
         s.top2 = cs.i[1][tid];
@@ -446,6 +485,7 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
 template <int MAXD, bool STATS, bool FROM_RAYS>
 __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const double* __restrict__ g_tab,
                                                         const DevShade* __restrict__ g_shade,
+                                                        const int* __restrict__ g_order,
                                                         const double* __restrict__ g_rays,
                                                         double* __restrict__ g_out, uint32_t* __restrict__ g_counter,
                                                         unsigned long long* __restrict__ g_stats, const DevWorld wc,
@@ -658,7 +698,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             if (STATS) ++n_radiance;
             const int remaining = base_rem - sp;
             Sweep hit;
-            sweep_world<false, STATS>(g_tab, w.n, ro, rd, hit, containers, n_sphere_hits, n_plane_hits);
+            sweep_world<false, STATS>(g_tab, g_order, w, ro, rd, hit, containers, n_sphere_hits, n_plane_hits);
             RTC_STAMP(pc_sweep1);
 
             have_ret = true;
@@ -700,7 +740,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 Sweep sh_hit;
                 sh_hit.t = distance;
                 RTC_STAMP(pc_prep);
-                sweep_world<true, STATS>(g_tab, w.n, over_point, lightv, sh_hit, containers, n_sphere_hits, n_plane_hits);
+                sweep_world<true, STATS>(g_tab, g_order, w, over_point, lightv, sh_hit, containers, n_sphere_hits, n_plane_hits);
                 RTC_STAMP(pc_sweep2);
                 const bool in_shadow = sh_hit.idx >= 0;
 
@@ -970,7 +1010,7 @@ hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t 
     const uint64_t needed = ((uint64_t)job.total + kBlock - 1) / kBlock;
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.tab, world.shade, job.rays,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.tab, world.shade, world.order, job.rays,
                        job.out, job.counter, (unsigned long long*)job.stats, world, job);
     return hipGetLastError();
 }

@@ -19,7 +19,7 @@ from golden_io import GOLDEN_DIR, NAMES, Fixture
 from raytracer_challenge_amd import (Camera, Canvas, Color, Mat4, Material, Pattern, PointLight, Shape, World,
                                      byte_color_values, canvas_to_ppm, descs as D, init_glass_sphere, init_point,
                                      init_vector, native, scenes, tiles, view_transform)
-from worlds import nested_glass_world, random_world
+from worlds import nested_glass_world, random_world, tie_world
 
 pytestmark = pytest.mark.gpu
 
@@ -234,6 +234,13 @@ def test_random_worlds(seed):
 def test_nested_glass_world():
     w, c = nested_glass_world()
     assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), "nested glass")
+
+
+def test_coincident_surfaces_ties_by_list_order():
+    """Equal t from different shapes: the reference's stable sort makes list order decide the
+    hit and the container nesting; the device visits the shapes in a different (grouped) order."""
+    w, c = tie_world()
+    assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), "tie world")
 
 
 @pytest.mark.parametrize("depth", [0, 1, 2, 3, 4, 5, 6, 8, 16])

@@ -11,7 +11,7 @@ import pytest
 
 import oracle_lib as O
 from raytracer_challenge_amd import Camera, descs as D, init_point, init_vector, scenes, view_transform
-from worlds import nested_glass_world, random_world
+from worlds import nested_glass_world, random_world, tie_world
 
 
 def _both(world, cam, depth=5):
@@ -42,6 +42,11 @@ def test_draw_world_scene_small():
 
 def test_nested_glass():
     w, c = nested_glass_world()
+    _both(w, c)
+
+
+def test_coincident_surfaces_ties_by_list_order():
+    w, c = tie_world()
     _both(w, c)
 
 

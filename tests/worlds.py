@@ -70,3 +70,36 @@ def nested_glass_world():
     cam = Camera(48, 32, 0.9)
     cam.transform = view_transform(init_point(0.3, 0.4, -7), init_point(0, 0, 0), init_vector(0, 1, 0))
     return w, cam
+
+
+def tie_world():
+    """Coincident surfaces: every root of one shape ties with a root of another, so the hit
+    and the container order are decided by list order alone (stable sort, ray.zig:75-92).
+    Mixed kinds (sheared / axis-aligned, spheres / planes) so that shapes that tie sit in
+    different groups of the device's sweep table."""
+    w = World()
+    w.light = PointLight(init_point(-5, 6, -8), Color(1, 1, 1))
+    big = Mat4.identity().scale(1.5, 1.5, 1.5)
+    # same geometry, different materials, glass in between opaque: list order decides
+    w.objects.append(Shape("sphere", big, Material(color=Color(0.9, 0.1, 0.1), transparency=0.8, reflective=0.3,
+                                                     refractive_index=1.4)))
+    w.objects.append(Shape("sphere", big, Material(color=Color(0.1, 0.9, 0.1), transparency=0.6, refractive_index=2.0)))
+    # the same sphere again as a general (rotated) matrix: rotation of a sphere leaves it in place
+    w.objects.append(Shape("sphere", Mat4.identity().scale(1.5, 1.5, 1.5).rotate_y(0.7),
+                           Material(color=Color(0.1, 0.1, 0.9), transparency=0.7, reflective=0.2, refractive_index=1.2,
+                                    pattern=Pattern("stripe", Color(1, 1, 0), Color(0, 1, 1)))))
+    # coincident planes: axis-aligned and (numerically) the same plane through a general matrix
+    w.objects.append(Shape("plane", Mat4.identity().translate(0, -2, 0),
+                           Material(color=Color(0.8, 0.8, 0.2), reflective=0.5)))
+    w.objects.append(Shape("plane", Mat4.identity().shear(0, 0, 0, 0, 0, 0).rotate_y(0.3).translate(0, -2, 0),
+                           Material(color=Color(0.2, 0.8, 0.8), transparency=0.5, refractive_index=1.1)))
+    # a glass plane behind the camera (a container that never closes) tied with another one
+    w.objects.append(Shape("plane", Mat4.identity().rotate_x(math.pi / 2).translate(0, 0, -9),
+                           Material(color=Color(0.5, 0.5, 0.5), transparency=0.9, refractive_index=1.7)))
+    w.objects.append(Shape("plane", Mat4.identity().rotate_x(math.pi / 2).translate(0, 0, -9),
+                           Material(color=Color(0.5, 0.2, 0.5), transparency=0.9, refractive_index=1.9)))
+    w.objects.append(Shape("sphere", Mat4.identity().scale(0.5, 0.5, 0.5).translate(0.2, 0.1, 0),
+                           Material(color=Color(1, 1, 1), transparency=0.9, reflective=0.9, refractive_index=1.5)))
+    cam = Camera(48, 32, 0.8)
+    cam.transform = view_transform(init_point(0.2, 0.5, -7), init_point(0, 0, 0), init_vector(0, 1, 0))
+    return w, cam
