@@ -140,6 +140,14 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                      RtcScene** out_scene);
 int rtc_scene_destroy(RtcScene* scene);
 
+/* How many shapes of the scene fall in each group of the sweep table: out[0] spheres whose
+ * inverse transform is diagonal (3x3 part), out[1] other spheres, out[2] planes whose inverse
+ * has row 1 = (0, m, 0, t), out[3] other planes.  The groups with exact zero entries skip the
+ * products with those zeros (the values are unchanged), so they execute fewer flops than the
+ * reference's 54 per ray-sphere and 11 per ray-plane test; a roofline that wants executed
+ * rather than algorithmic flops needs these counts. */
+int rtc_scene_group_counts(const RtcScene* scene, uint64_t out_counts[4]);
+
 /* Camera.render (camera.zig:74-89): fill out_rgb (host memory, hsize*vsize*3 doubles,
  * pixel (x,y) at index (y*hsize + x)*3 as canvas.zig:25, channels red,green,blue as
  * color.zig:7-9) with calc.worldColorAt(world, rayForPixel(x,y), depth).  The

@@ -468,6 +468,12 @@ int rtc_scene_destroy(RtcScene* scene) {
     return RTC_OK;
 }
 
+int rtc_scene_group_counts(const RtcScene* scene, uint64_t out_counts[4]) {
+    if (!scene || !out_counts) return fail(RTC_ERR_INVALID_ARGUMENT, "NULL pointer");
+    for (int g = 0; g < 4; ++g) out_counts[g] = (uint64_t)(scene->group[g + 1] - scene->group[g]);
+    return RTC_OK;
+}
+
 int rtc_tile_buffer_doubles(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks,
                             uint64_t* out_doubles) {
     if (!out_doubles) return fail(RTC_ERR_INVALID_ARGUMENT, "out_doubles is NULL");

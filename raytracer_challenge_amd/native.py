@@ -45,6 +45,7 @@ def lib():
     L.rtc_set_device.argtypes = [i32]
     L.rtc_scene_create.argtypes = [C.POINTER(D.RtcShapeDesc), u64, C.POINTER(D.RtcLightDesc), C.POINTER(vp)]
     L.rtc_scene_destroy.argtypes = [vp]
+    L.rtc_scene_group_counts.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
     L.rtc_render.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, dp, C.POINTER(D.RtcStats)]
     L.rtc_render_device.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
     L.rtc_tile_buffer_doubles.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, C.POINTER(u64)]
@@ -67,6 +68,7 @@ EXPORTS = (
     "rtc_set_device",
     "rtc_scene_create",
     "rtc_scene_destroy",
+    "rtc_scene_group_counts",
     "rtc_render",
     "rtc_render_device",
     "rtc_tile_buffer_doubles",
@@ -151,6 +153,12 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    def group_counts(self):
+        """rtc_scene_group_counts: (axis spheres, general spheres, axis planes, general planes)."""
+        out = (C.c_uint64 * 4)()
+        check(lib().rtc_scene_group_counts(self._h, C.byref(out)))
+        return tuple(int(v) for v in out)
 
     def render(self, camera_desc, depth=5, stats=None):
         """rtc_render: returns the canvas as a (vsize, hsize, 3) float64 array."""
