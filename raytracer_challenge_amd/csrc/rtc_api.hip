@@ -448,7 +448,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     } while (0)
     SCENE_TRY(hipMalloc((void**)&sc->d_tab, tab.size() * sizeof(double)));
     SCENE_TRY(hipMalloc((void**)&sc->d_shade, n_alloc * sizeof(rtc::DevShade)));
-    SCENE_TRY(hipMalloc((void**)&sc->d_counter, 64 + 11 * 8 * 8192));  // queue head, stats, developer probe area
+    SCENE_TRY(hipMalloc((void**)&sc->d_counter, 64 + 19 * 8 * 8192));  // queue head, stats, developer probe area
     sc->d_stats = (uint64_t*)((char*)sc->d_counter + 8);
     SCENE_TRY(hipEventCreate(&sc->ev_start));
     SCENE_TRY(hipEventCreate(&sc->ev_stop));
@@ -598,7 +598,7 @@ int rtc_arith_probe(const double* a, const double* b, uint64_t n, double* out_di
 #ifdef RTC_PROBE
 int rtc_debug_probe(RtcScene* scene, uint64_t* out, uint64_t n_waves) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, (char*)scene->d_counter + 64, 11 * 8 * 8192, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, (char*)scene->d_counter + 64, 19 * 8 * 8192, hipMemcpyDeviceToHost));
     return RTC_OK;
 }
 #endif

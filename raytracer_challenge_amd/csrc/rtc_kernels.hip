@@ -479,10 +479,24 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
     return pos;
 }
 
+// Worlds of at most kLdsShapes shapes keep what a hit gathers per lane (the shape's inverse
+// and its material/pattern record) in LDS, copied once per workgroup: a gather then costs an
+// LDS access instead of a chain of dependent trips to the L2, which four waves per SIMD
+// cannot hide.  Larger worlds spend their time in the sweeps and gather from global memory.
+constexpr int kLdsShapes = 32;
+template <bool ON>
+struct HotTables {};
+template <>
+struct HotTables<true> {
+    double mat[kLdsShapes][12];
+    DevShade shade[kLdsShapes];
+};
+static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
+
 // The read-only tables and the output are separate __restrict__ kernel arguments so that
 // the compiler can prove the wave-uniform table reads are never clobbered by the kernel's
 // own stores and keep them on the scalar path; the structs carry the remaining scalars.
-template <int MAXD, bool STATS, bool FROM_RAYS>
+template <int MAXD, bool STATS, bool FROM_RAYS, bool LDS>
 __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const double* __restrict__ g_tab,
                                                         const DevShade* __restrict__ g_shade,
                                                         const int* __restrict__ g_order,
@@ -491,6 +505,27 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                                                         unsigned long long* __restrict__ g_stats, const DevWorld wc,
                                                         const DevJob job) {
     __shared__ ContainerSlots containers;
+    __shared__ HotTables<LDS> hot;
+    if constexpr (LDS) {
+        const int n = wc.n;
+        for (int k = (int)threadIdx.x; k < n * 12; k += kBlock) hot.mat[k / 12][k % 12] = g_tab[(k / 12) * kRecDoubles + k % 12];
+        const double* __restrict__ src = reinterpret_cast<const double*>(g_shade);
+        double* dst = reinterpret_cast<double*>(hot.shade);
+        for (int k = (int)threadIdx.x; k < n * (int)(sizeof(DevShade) / 8); k += kBlock) dst[k] = src[k];
+        __syncthreads();
+    }
+    auto shade_of = [&](int i) -> const DevShade& {
+        if constexpr (LDS)
+            return hot.shade[i];
+        else
+            return g_shade[i];
+    };
+    auto inverse_of = [&](int i) -> const double* {
+        if constexpr (LDS)
+            return hot.mat[i];
+        else
+            return g_tab + (size_t)i * kRecDoubles;
+    };
     const int lane = (int)(threadIdx.x & 63);
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     DevWorld w = wc;
@@ -527,13 +562,16 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #ifdef RTC_PROBE
     const unsigned long long probe_t0 = wall_clock64();
     unsigned long long probe_tx = 0;
-    unsigned long long pc_refill = 0, pc_sweep1 = 0, pc_prep = 0, pc_sweep2 = 0, pc_shade = 0, pc_unwind = 0, pc_iters = 0;
+    unsigned long long pcv[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long pc_mark = clock64();
+    enum { pc_refill, pc_sweep1, pc_prep, pc_sweep2, pc_gather, pc_pattern, pc_light, pc_children, pc_push, pc_unwind, pc_iters = 15 };
 #define RTC_STAMP(acc)                          \
     do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
         const unsigned long long _now = clock64(); \
-        acc += _now - pc_mark;                  \
+        pcv[acc] += _now - pc_mark;             \
         pc_mark = _now;                         \
+        __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
 #else
 #define RTC_STAMP(acc) \
@@ -691,7 +729,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 
         RTC_STAMP(pc_refill);
 #ifdef RTC_PROBE
-        ++pc_iters;
+        ++pcv[pc_iters];
 #endif
         if (mode == kRun && !waiting && !have_ret) {
             // ---- one tree node: calc.worldColorAt (calc.zig:641-652) ---------------------
@@ -706,8 +744,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 if (STATS) ++n_shaded;
                 const bool exit_open = (hit.idx & kExitOpenBit) != 0;
                 hit.idx &= ~kExitOpenBit;
-                const DevShade& sh = w.shade[hit.idx];
-                const double* __restrict__ oinv = g_tab + (size_t)hit.idx * kRecDoubles;
+                const DevShade& sh = shade_of(hit.idx);
+                const double* __restrict__ oinv = inverse_of(hit.idx);
                 // gather what the normal needs in one batch (the loads overlap each other)
                 double M[12];
 #pragma unroll
@@ -752,8 +790,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 V3 color = {sh.color[0], sh.color[1], sh.color[2]};
                 // n1 / n2 from the open containers
                 const int rest = (hit.top1 == hit.idx) ? hit.top2 : hit.top1;
-                const double ri_top1 = hit.top1 < 0 ? 1.0 : w.shade[hit.top1].refractive_index;
-                const double ri_rest = rest < 0 ? 1.0 : w.shade[rest].refractive_index;
+                const double ri_top1 = hit.top1 < 0 ? 1.0 : shade_of(hit.top1).refractive_index;
+                const double ri_rest = rest < 0 ? 1.0 : shade_of(rest).refractive_index;
                 const double n1 = ri_top1;
                 const double n2 = exit_open ? ri_rest : m_ri;
                 // the rest of calc.prepareComputations (deferred past the shadow sweep: fewer live registers)
@@ -761,9 +799,11 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 const V3 reflectv = {rd.x - two_dp * normalv.x, rd.y - two_dp * normalv.y, rd.z - two_dp * normalv.z};
                 const V3 under_point = {point.x - offs.x, point.y - offs.y, point.z - offs.z};
 
+                RTC_STAMP(pc_gather);
                 // ---- calc.lighting (calc.zig:26-73) at over_point; lightv above is the same
                 // light.position.sub(position).normalize() the reference recomputes
                 if (m_pattern >= 0) color = pattern_color(sh, oinv, over_point);
+                RTC_STAMP(pc_pattern);
                 const V3 eff = {color.x * lint.x, color.y * lint.y, color.z * lint.z};
                 V3 surface = {m_ambient * eff.x, m_ambient * eff.y, m_ambient * eff.z};
                 const double light_dot_normal = dot3(lightv, normalv);
@@ -780,6 +820,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     }
                 }
 
+                RTC_STAMP(pc_light);
                 // ---- children: calc.reflectedColor (945-959), calc.refractedColor (828-853)
                 const bool has_reflect = remaining > 0 && !(fabs(m_reflective) <= kF64Eps);
                 bool has_refract = false;
@@ -818,20 +859,25 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                         R = r0 + (1 - r0) * zig_pow(1 - cosv, 5.0);
                     }
                 }
+                RTC_STAMP(pc_children);
                 if (has_reflect || has_refract) {
+                    // a frame holds only what its unwinding will read: most frames (a reflective,
+                    // opaque surface) are the colour so far, one factor and the flags
                     f_acc[sp][0] = surface.x;
                     f_acc[sp][1] = surface.y;
                     f_acc[sp][2] = surface.z;
-                    f_refl[sp] = m_reflective;
-                    f_transp[sp] = m_transparency;
-                    f_R[sp] = R;
+                    if (flags & kSchlick) f_R[sp] = R;
+                    if (has_refract) f_transp[sp] = m_transparency;
                     if (has_reflect) {
-                        f_ray[sp][0] = under_point.x;
-                        f_ray[sp][1] = under_point.y;
-                        f_ray[sp][2] = under_point.z;
-                        f_ray[sp][3] = refr_dir.x;
-                        f_ray[sp][4] = refr_dir.y;
-                        f_ray[sp][5] = refr_dir.z;
+                        f_refl[sp] = m_reflective;
+                        if (has_refract) {
+                            f_ray[sp][0] = under_point.x;
+                            f_ray[sp][1] = under_point.y;
+                            f_ray[sp][2] = under_point.z;
+                            f_ray[sp][3] = refr_dir.x;
+                            f_ray[sp][4] = refr_dir.y;
+                            f_ray[sp][5] = refr_dir.z;
+                        }
                         f_flags[sp] = flags;
                         ro = over_point;
                         rd = reflectv;
@@ -853,7 +899,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             }
         }
 
-        RTC_STAMP(pc_shade);
+        RTC_STAMP(pc_push);
         // ---- unwind finished subtrees in the reference's post-order -----------------------
         if (have_ret) {
             bool settled = false;  // the lane descended into a child or waits for a helper
@@ -934,8 +980,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             pr[wid * 3 + 0] = probe_t0;
             pr[wid * 3 + 1] = probe_tx;
             pr[wid * 3 + 2] = wall_clock64();
-            unsigned long long* pc = pr + 3 * 8192 + wid * 8;
-            pc[0] = pc_refill; pc[1] = pc_sweep1; pc[2] = pc_prep; pc[3] = pc_sweep2; pc[4] = pc_shade; pc[5] = pc_unwind; pc[6] = pc_iters;
+            unsigned long long* pc = pr + 3 * 8192 + wid * 16;
+            for (int q = 0; q < 16; ++q) pc[q] = pcv[q];
         }
     }
 #endif
@@ -993,9 +1039,9 @@ __global__ __launch_bounds__(kBlock) void arith_probe_kernel(const double* __res
     }
 }
 
-template <int MAXD, bool STATS, bool FROM_RAYS>
-hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t stream) {
-    auto kernel = render_kernel<MAXD, STATS, FROM_RAYS>;
+template <int MAXD, bool STATS, bool FROM_RAYS, bool LDS>
+hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t stream) {
+    auto kernel = render_kernel<MAXD, STATS, FROM_RAYS, LDS>;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -1013,6 +1059,12 @@ hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t 
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.tab, world.shade, world.order, job.rays,
                        job.out, job.counter, (unsigned long long*)job.stats, world, job);
     return hipGetLastError();
+}
+
+template <int MAXD, bool STATS, bool FROM_RAYS>
+hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t stream) {
+    if (world.n <= kLdsShapes) return launch_tables<MAXD, STATS, FROM_RAYS, true>(world, job, stream);
+    return launch_tables<MAXD, STATS, FROM_RAYS, false>(world, job, stream);
 }
 
 }  // namespace

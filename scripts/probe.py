@@ -13,7 +13,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 L = native.lib()
 n = 4096
-raw = np.zeros(11 * 8192, dtype=np.uint64)
+raw = np.zeros(19 * 8192, dtype=np.uint64)
 buf = raw[: 3 * 8192].reshape(8192, 3)[:n]
 L.rtc_debug_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
 assert L.rtc_debug_probe(sc._h, raw.ctypes.data, n) == 0
@@ -27,10 +27,10 @@ print("end at ms: min %.3f p10 %.3f med %.3f p90 %.3f p99 %.3f max %.3f" % tuple
 tail = (te[ok] - tx[ok]) * f
 print("per-wave (end - exhausted) ms: med %.3f p90 %.3f max %.3f" % tuple(np.percentile(tail, [50, 90, 100])))
 
-pc = raw[3 * 8192:].reshape(8192, 8)[:n][ok].astype(np.float64)
-names = ["refill+steal", "sweep1", "prep", "sweep2", "shade", "unwind"]
-tot = pc[:, :6].sum()
-iters = pc[:, 6].sum()
+pc = raw[3 * 8192:].reshape(8192, 16)[:n][ok].astype(np.float64)
+names = ["refill+steal", "sweep1", "prep", "sweep2", "gather", "pattern", "light", "children", "push", "unwind"]
+tot = pc[:, :10].sum()
+iters = pc[:, 15].sum()
 print("wave-iterations", int(iters), " cycles per wave-iteration %.0f" % (tot / iters))
 for k, nme in enumerate(names):
     print("  %-13s %5.1f%%  %8.0f cycles/iter" % (nme, 100 * pc[:, k].sum() / tot, pc[:, k].sum() / iters))

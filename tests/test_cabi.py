@@ -87,3 +87,20 @@ def test_argument_validation_needs_no_gpu():
     assert n.value == ((15 * 57) // 2) * 64 * 8 * 3
     h = C.c_void_p()
     assert L.rtc_scene_create(None, 3, None, C.byref(h)) == D.RTC_ERR_INVALID_ARGUMENT
+
+
+def test_cpp_host_program_fails_loudly_without_a_gpu(tmp_path):
+    """host/draw_world has no CPU path: without a device it must exit non-zero with the
+    library's error text and write no image."""
+    try:
+        if native.device_count() > 0:
+            pytest.skip("a GPU is present")
+    except native.RtcError:
+        pass
+    host_dir = os.path.join(os.path.dirname(native.lib_path()), "host")
+    subprocess.run(["make", "-C", host_dir], check=True, capture_output=True)
+    out = tmp_path / "result.ppm"
+    r = subprocess.run([os.path.join(host_dir, "draw_world"), "32", "16", str(out)], capture_output=True, text=True,
+                       timeout=60)
+    assert r.returncode == 1 and "render failed" in r.stderr
+    assert not out.exists()

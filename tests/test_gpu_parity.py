@@ -10,6 +10,7 @@ import io
 import json
 import math
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -224,6 +225,20 @@ def test_draw_world_at_the_reference_resolution():
         assert hashlib.sha256(image.pixels.tobytes()).hexdigest() == meta["canvas_f64_sha256"]
         assert hashlib.sha256(a.getvalue().encode()).hexdigest() == meta["ppm_sha256"]
 
+
+def test_cpp_host_program_writes_the_same_ppm(tmp_path):
+    """host/draw_world (C++ restatement of draw_world.zig:23-202 over the C-ABI) against the
+    oracle's canvas written by the Python P3 writer: the files must be byte-identical."""
+    exe = os.path.join(os.path.dirname(native.lib_path()), "host", "draw_world")
+    if not os.path.exists(exe):  # plain g++ over the already built library: seconds
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True, capture_output=True)
+    out = tmp_path / "result.ppm"
+    r = subprocess.run([exe, "300", "150", str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    w, c = scenes.draw_world_scene(300, 150)
+    b = io.StringIO()
+    canvas_to_ppm(Canvas(300, 150, O.render(w, c, 5, O.STREAMING)), b)
+    assert out.read_text() == b.getvalue()
 
 @pytest.mark.parametrize("seed", range(6))
 def test_random_worlds(seed):
