@@ -135,7 +135,7 @@ int rtc_set_device(int32_t device);
  * computed once on the host with the reference's cofactor algorithm (matrix.zig:286-300),
  * which yields the same bits as the reference's per-call recomputation.  Rejects
  * singular and non-affine transforms and value-identical duplicate shapes.
- * n_shapes may be 0 (every ray misses, calc.zig:649-651). */
+ * n_shapes may be 0 (every ray misses, calc.zig:649-651) and at most 2^21. */
 int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLightDesc* light,
                      RtcScene** out_scene);
 int rtc_scene_destroy(RtcScene* scene);

@@ -6,7 +6,9 @@
 // cofactor algorithm, so the bits are the same.
 #include "rtc_internal.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -184,6 +186,19 @@ struct RtcScene {
     double light_pos[3] = {0, 0, 0};
     double light_int[3] = {0, 0, 0};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // Shapes whose hits branch into two subtrees (transparent materials): world-space bounding
+    // spheres, used to hand out the tiles that show them first (see plan_tile_order).
+    struct Costly {
+        double c[3], r;
+    };
+    std::vector<Costly> costly;
+    bool costly_everywhere = false;  // a transparent plane: no useful bound
+    // the plan of the last camera / partition, reused while they do not change
+    uint32_t* d_tile_order = nullptr;
+    uint64_t tile_order_capacity = 0;
+    bool plan_valid = false, plan_identity = true;
+    RtcCameraDesc plan_camera{};
+    uint32_t plan_rank = 0, plan_ranks = 0;
 };
 
 namespace {
@@ -194,6 +209,7 @@ void free_scene(RtcScene* s) {
     if (s->d_order) (void)hipFree(s->d_order);
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_counter) (void)hipFree(s->d_counter);
+    if (s->d_tile_order) (void)hipFree(s->d_tile_order);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     delete s;
@@ -244,6 +260,127 @@ int read_stats(RtcScene* s, RtcStats* out, uint64_t pixels, float ms) {
     out->shaded_hits = h[4];
     out->pixels = pixels;
     out->kernel_ms = ms;
+    return RTC_OK;
+}
+
+// Largest factor by which the 3x3 part of a row-major 4x4 stretches a vector (its largest
+// singular value), by power iteration on A^T A; scheduling heuristics only.
+double largest_stretch(const double* m) {
+    double v[3] = {0.6, 0.55, 0.58}, norm = 0;
+    for (int it = 0; it < 24; ++it) {
+        double av[3], w[3];
+        for (int r = 0; r < 3; ++r) av[r] = m[r * 4] * v[0] + m[r * 4 + 1] * v[1] + m[r * 4 + 2] * v[2];
+        for (int c = 0; c < 3; ++c) w[c] = m[c] * av[0] + m[4 + c] * av[1] + m[8 + c] * av[2];
+        norm = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        if (!(norm > 0) || !std::isfinite(norm)) return 0;
+        for (int c = 0; c < 3; ++c) v[c] = w[c] / norm;
+    }
+    return std::sqrt(norm);
+}
+
+// The persistent kernel hands out tiles from a queue; whichever tiles come last decide how
+// long the GPU runs partly empty at the end, because one pixel is a serial chain of up to 2^depth
+// nodes.  Pixels that show a transparent shape cost several times the average (each such hit has two
+// subtrees), so the rows of tiles that can show one are queued first, the fullest first, and
+// the remaining rows follow by their distance from those, nearest first.  Rows stay whole and
+// are scanned left to right: measured on the 4K reference frame, a queue that keeps a row's
+// tiles together is faster than one that scatters them, and queueing the costly rows first is
+// worth about 7 % of the frame time over a top-to-bottom scan.
+// This only orders the work: every pixel is computed by the same arithmetic whatever its
+// place in the queue.  Sets job->tile_order (nullptr = natural order).  The plan is cached
+// per camera and partition.
+int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uint64_t local_tiles,
+                    hipStream_t stream) {
+    job->tile_order = nullptr;
+    if (local_tiles < 2 || s->costly_everywhere || s->costly.empty()) return RTC_OK;
+    if (s->plan_valid && s->plan_rank == job->tile_rank && s->plan_ranks == job->tile_ranks &&
+        std::memcmp(&s->plan_camera, cam, sizeof *cam) == 0) {
+        job->tile_order = s->plan_identity ? nullptr : s->d_tile_order;
+        return RTC_OK;
+    }
+    const uint32_t tiles_x = job->tiles_x, ranks = job->tile_ranks, rank = job->tile_rank;
+    const uint32_t tiles_y = job->tiles_total / tiles_x;
+    std::vector<uint64_t> row_score(tiles_y, 0);
+    const double* T = cam->transform;  // world -> camera; the camera looks down -z (camera.zig:48-72)
+    const double stretch = largest_stretch(T);
+    bool any = false;
+    for (const RtcScene::Costly& k : s->costly) {
+        const double xc = T[0] * k.c[0] + T[1] * k.c[1] + T[2] * k.c[2] + T[3];
+        const double yc = T[4] * k.c[0] + T[5] * k.c[1] + T[6] * k.c[2] + T[7];
+        const double dist = -(T[8] * k.c[0] + T[9] * k.c[1] + T[10] * k.c[2] + T[11]);
+        const double r = k.r * stretch * 1.05;
+        if (!(dist + r > 0)) continue;  // entirely behind the eye
+        double x0 = -1e300, x1 = 1e300, y0 = -1e300, y1 = 1e300;  // extent on the plane z = -1
+        if (dist - r > 1e-9) {
+            const double near = dist - r, far = dist + r;
+            x0 = std::fmin((xc - r) / near, (xc - r) / far);
+            x1 = std::fmax((xc + r) / near, (xc + r) / far);
+            y0 = std::fmin((yc - r) / near, (yc - r) / far);
+            y1 = std::fmax((yc + r) / near, (yc + r) / far);
+        }
+        // pixel = (half - offset) / pixel_size, larger coordinate = smaller pixel index
+        const double px0 = (cam->half_width - x1) / cam->pixel_size, px1 = (cam->half_width - x0) / cam->pixel_size;
+        const double py0 = (cam->half_height - y1) / cam->pixel_size, py1 = (cam->half_height - y0) / cam->pixel_size;
+        if (!(px1 >= 0) || !(py1 >= 0) || !(px0 < (double)cam->hsize) || !(py0 < (double)cam->vsize)) continue;
+        const uint32_t tx0 = px0 > 0 ? (uint32_t)(px0 / RTC_TILE_W) : 0;
+        const uint32_t ty0 = py0 > 0 ? (uint32_t)(py0 / RTC_TILE_H) : 0;
+        const uint32_t tx1 = px1 < (double)cam->hsize ? (uint32_t)(px1 / RTC_TILE_W) : tiles_x - 1;
+        const uint32_t ty1 = py1 < (double)cam->vsize ? (uint32_t)(py1 / RTC_TILE_H) : tiles_y - 1;
+        for (uint32_t ty = ty0; ty <= ty1 && ty < tiles_y; ++ty) row_score[ty] += (uint64_t)(tx1 - tx0 + 1);
+        any = true;
+    }
+    s->plan_camera = *cam;
+    s->plan_rank = rank;
+    s->plan_ranks = ranks;
+    s->plan_valid = true;
+    s->plan_identity = !any;
+    if (!any) return RTC_OK;
+    // rank of every row of tiles in the queue
+    std::vector<uint32_t> dist_to_costly(tiles_y, tiles_y);
+    {
+        uint32_t d = tiles_y;
+        for (uint32_t y = 0; y < tiles_y; ++y) {
+            d = row_score[y] ? 0 : (d < tiles_y ? d + 1 : d);
+            dist_to_costly[y] = d;
+        }
+        d = tiles_y;
+        for (uint32_t y = tiles_y; y-- > 0;) {
+            d = row_score[y] ? 0 : (d < tiles_y ? d + 1 : d);
+            dist_to_costly[y] = std::min(dist_to_costly[y], d);
+        }
+    }
+    std::vector<uint32_t> rows(tiles_y);
+    for (uint32_t y = 0; y < tiles_y; ++y) rows[y] = y;
+    std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) {
+        if ((row_score[a] != 0) != (row_score[b] != 0)) return row_score[a] != 0;
+        if (row_score[a] != row_score[b]) return row_score[a] > row_score[b];
+        return dist_to_costly[a] < dist_to_costly[b];
+    });
+    std::vector<uint32_t> rank_of_row(tiles_y);
+    for (uint32_t i = 0; i < tiles_y; ++i) rank_of_row[rows[i]] = i;
+    // local tiles bucketed by the rank of their row, left to right inside a row
+    std::vector<uint64_t> start(tiles_y + 1, 0);
+    for (uint64_t k = 0; k < local_tiles; ++k) ++start[rank_of_row[(k * ranks + rank) / tiles_x] + 1];
+    for (uint32_t i = 0; i < tiles_y; ++i) start[i + 1] += start[i];
+    std::vector<uint32_t> order(local_tiles);
+    for (uint64_t k = 0; k < local_tiles; ++k) order[start[rank_of_row[(k * ranks + rank) / tiles_x]]++] = (uint32_t)k;
+    // an earlier launch on this stream may still be reading the previous plan
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (s->tile_order_capacity < local_tiles) {
+        s->plan_valid = false;
+        if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+        s->d_tile_order = nullptr;
+        s->tile_order_capacity = 0;
+        HIP_TRY(hipMalloc((void**)&s->d_tile_order, local_tiles * sizeof(uint32_t)));
+        s->tile_order_capacity = local_tiles;
+        s->plan_valid = true;
+    }
+    hipError_t e = hipMemcpy(s->d_tile_order, order.data(), local_tiles * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        s->plan_valid = false;
+        return fail_hip("hipMemcpy(tile order)", e);
+    }
+    job->tile_order = s->d_tile_order;
     return RTC_OK;
 }
 
@@ -328,7 +465,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     *out_scene = nullptr;
     if (!light) return fail(RTC_ERR_INVALID_ARGUMENT, "light is NULL");
     if (n_shapes > 0 && !shapes) return fail(RTC_ERR_INVALID_ARGUMENT, "shapes is NULL");
-    if (n_shapes > (1u << 24)) return fail(RTC_ERR_TOO_LARGE, "more than 2^24 shapes");
+    if (n_shapes > (1u << 21)) return fail(RTC_ERR_TOO_LARGE, "more than 2^21 shapes");
     if (!(light->position[3] == 1.0))
         return fail(RTC_ERR_INVALID_ARGUMENT, "light.position must be a point (w == 1)");
 
@@ -430,6 +567,17 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         free_scene(sc);
         return fail_hip("hipGetDevice", e);
     }
+    for (uint64_t i = 0; i < n_shapes; ++i) {
+        const RtcShapeDesc& s = shapes[i];
+        if (!(std::fabs(s.material.transparency) > kF64Eps)) continue;
+        if (s.geo == RTC_GEO_PLANE) {
+            sc->costly_everywhere = true;
+            continue;
+        }
+        // unit sphere under the shape's transform: centre = translation column
+        const double* t = s.transform;
+        sc->costly.push_back({{t[3], t[7], t[11]}, largest_stretch(t)});
+    }
     sc->n = n_shapes;
     sc->n_spheres = n_spheres;
     sc->n_planes = n_planes;
@@ -499,6 +647,8 @@ int rtc_render_device(RtcScene* scene, const RtcCameraDesc* camera, int32_t dept
     uint64_t local_pixels = 0;
     if (int rc = fill_camera_job(camera, depth, tile_rank, tile_ranks, &job, &local_pixels)) return rc;
     job.out = (double*)d_out_rgb;
+    if (int rc = plan_tile_order(scene, camera, &job, local_pixels / (RTC_TILE_W * RTC_TILE_H), (hipStream_t)hip_stream))
+        return rc;
     const uint64_t pixels = tile_ranks == 1 ? camera->hsize * camera->vsize : local_pixels;
     return run_job(scene, job, (hipStream_t)hip_stream, stats, pixels);
 }

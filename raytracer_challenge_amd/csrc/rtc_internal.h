@@ -59,6 +59,9 @@ struct DevJob {
     // explicit rays instead of camera rays (rtc_color_at): 6 doubles per ray, or nullptr
     const double* rays;
     uint32_t total;  // number of work items: local tile pixels (padding included) or rays
+    // Order in which the queue hands out the local tiles (queue slot -> local tile index),
+    // costliest first, or nullptr for the natural order.  Only the schedule depends on it.
+    const uint32_t* tile_order;
     int32_t depth;
     double* out;
     uint32_t* counter;  // work-queue head, zeroed before the launch

@@ -455,14 +455,24 @@ __device__ __forceinline__ V3 pattern_color(const DevShade& sh, const double* __
 
 // Frame of a node whose children are still being traced.
 //   acc      surface colour, then surface + reflected term (calc.zig:466,468)
-//   refl     material.reflective (scales the reflected child, calc.zig:958)
+//   meta     flags, the lane tracing an outsourced subtree, and the table position of the hit
+//            shape (its material gives the factor of the reflected child, calc.zig:958)
 //   transp   material.transparency (scales the refracted child, calc.zig:852)
 //   R        Schlick reflectance when flags & kSchlick (calc.zig:464-466)
 //   ray      the refracted ray, parked while the reflected subtree is traced
 // flags: kHasRefract — a refracted child exists; kWaitRefract — the reflected term is already
 // in acc and the frame waits for the refracted colour; kOutsourced — another lane of the wave
-// traces the refracted subtree (its lane id sits in bits 8..13).
+// traces the refracted subtree (its lane id sits in the partner bits).
+// acc and meta are what every frame uses; for the first kLdsFrames levels they live in LDS.
+// In private memory the frame stacks of all resident lanes together are several times the
+// L2, and every push and pop would travel to HBM and back.
 enum : int { kHasRefract = 1, kSchlick = 2, kWaitRefract = 4, kOutsourced = 8 };
+constexpr int kMetaPartnerShift = 4, kMetaShapeShift = 10;  // meta = flags | lane << 4 | shape << 10
+constexpr int kLdsFrames = 3;
+struct FrameSlots {
+    double acc[kLdsFrames][3][kBlock];
+    int meta[kLdsFrames][kBlock];
+};
 enum : int { kIdle = 0, kRun = 1, kHelperDone = 2 };
 constexpr int kChunk = 64;  // queue positions a wave draws at a time: one 8x8 block of pixels
 
@@ -501,11 +511,14 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                                                         const DevShade* __restrict__ g_shade,
                                                         const int* __restrict__ g_order,
                                                         const double* __restrict__ g_rays,
+                                                        const uint32_t* __restrict__ g_tile_order,
                                                         double* __restrict__ g_out, uint32_t* __restrict__ g_counter,
                                                         unsigned long long* __restrict__ g_stats, const DevWorld wc,
                                                         const DevJob job) {
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS> hot;
+    __shared__ FrameSlots frames;
+    const int tid = (int)threadIdx.x;
     if constexpr (LDS) {
         const int n = wc.n;
         for (int k = (int)threadIdx.x; k < n * 12; k += kBlock) hot.mat[k / 12][k % 12] = g_tab[(k / 12) * kRecDoubles + k % 12];
@@ -532,13 +545,39 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     w.tab = g_tab;
     w.shade = g_shade;
 
-    // per-lane frame stack (private memory: touched once per node, a few dozen bytes)
-    double f_acc[MAXD][3];
+    // per-lane frame stack: levels below kLdsFrames keep acc/meta in LDS, the rest is private memory
+    constexpr int kDeep = MAXD > kLdsFrames ? MAXD - kLdsFrames : 1;
+    double f_acc[kDeep][3];
+    int f_meta[kDeep];
     double f_ray[MAXD][6];
-    double f_refl[MAXD], f_transp[MAXD], f_R[MAXD];
-    int f_flags[MAXD];
+    double f_transp[MAXD], f_R[MAXD];
+    auto frame_meta = [&](int f) -> int { return f < kLdsFrames ? frames.meta[f][tid] : f_meta[f - kLdsFrames]; };
+    auto set_frame_meta = [&](int f, int v) {
+        if (f < kLdsFrames)
+            frames.meta[f][tid] = v;
+        else
+            f_meta[f - kLdsFrames] = v;
+    };
+    auto frame_acc = [&](int f) -> V3 {
+        if (f < kLdsFrames) return V3{frames.acc[f][0][tid], frames.acc[f][1][tid], frames.acc[f][2][tid]};
+        return V3{f_acc[f - kLdsFrames][0], f_acc[f - kLdsFrames][1], f_acc[f - kLdsFrames][2]};
+    };
+    auto set_frame_acc = [&](int f, const V3& v) {
+        if (f < kLdsFrames) {
+            frames.acc[f][0][tid] = v.x;
+            frames.acc[f][1][tid] = v.y;
+            frames.acc[f][2][tid] = v.z;
+        } else {
+            f_acc[f - kLdsFrames][0] = v.x;
+            f_acc[f - kLdsFrames][1] = v.y;
+            f_acc[f - kLdsFrames][2] = v.z;
+        }
+    };
 
     uint32_t n_radiance = 0, n_shadow = 0, n_sphere_hits = 0, n_plane_hits = 0, n_shaded = 0;
+#ifdef RTC_COSTMAP
+    int cost_nodes = 0;
+#endif
 
     // Task state of the lane.  A task is a subtree of the reference's recursion: either a
     // whole pixel (root) or, once the pixel queue is empty, a refracted subtree taken over
@@ -616,7 +655,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 } else {
                     // queue position k -> (local tile, 8x8 block of the tile, pixel of the block)
                     const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
-                    const uint32_t lt = k / tile_px, r = k % tile_px;
+                    const uint32_t slot = k / tile_px, r = k % tile_px;
+                    const uint32_t lt = g_tile_order ? g_tile_order[slot] : slot;
                     const uint32_t tx = (r / 64) * 8 + (r % 8), ty = (r % 64) / 8;
                     const uint32_t gt = lt * job.tile_ranks + job.tile_rank;
                     const uint32_t px = (gt % job.tiles_x) * RTC_TILE_W + tx;
@@ -638,6 +678,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     }
                 }
                 if (got_work) {
+#ifdef RTC_COSTMAP
+                    cost_nodes = 0;
+#endif
                     mode = kRun;
                     is_helper = false;
                     waiting = false;
@@ -670,11 +713,12 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 const int f = sp - 1;
                 const double kt = f_transp[f];
                 V3 c = {kt * hx, kt * hy, kt * hz};
-                if (f_flags[f] & kSchlick) {
+                if (frame_meta(f) & kSchlick) {
                     const double T = 1.0 - f_R[f];
                     c = {T * c.x, T * c.y, T * c.z};
                 }
-                ret = {f_acc[f][0] + c.x, f_acc[f][1] + c.y, f_acc[f][2] + c.z};
+                const V3 a0 = frame_acc(f);
+                ret = {a0.x + c.x, a0.y + c.y, a0.z + c.z};
                 --sp;
                 waiting = false;
                 have_ret = true;
@@ -683,7 +727,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             int offer_f = -1;
             if (mode == kRun) {
                 for (int f = sp - 1; f >= 0; --f) {
-                    const int fl = f_flags[f];
+                    const int fl = frame_meta(f);
                     if ((fl & kHasRefract) && !(fl & (kWaitRefract | kOutsourced))) offer_f = f;
                 }
             }
@@ -702,7 +746,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 if (give) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) p[q] = f_ray[offer_f][q];
-                    f_flags[offer_f] |= kOutsourced | (partner << 8);
+                    set_frame_meta(offer_f, frame_meta(offer_f) | kOutsourced | (partner << kMetaPartnerShift));
                 }
                 const int p_rem = base_rem - offer_f - 1;
                 double t6[6];
@@ -734,6 +778,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
         if (mode == kRun && !waiting && !have_ret) {
             // ---- one tree node: calc.worldColorAt (calc.zig:641-652) ---------------------
             if (STATS) ++n_radiance;
+#ifdef RTC_COSTMAP
+            ++cost_nodes;
+#endif
             const int remaining = base_rem - sp;
             Sweep hit;
             sweep_world<false, STATS>(g_tab, g_order, w, ro, rd, hit, containers, n_sphere_hits, n_plane_hits);
@@ -862,14 +909,11 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 RTC_STAMP(pc_children);
                 if (has_reflect || has_refract) {
                     // a frame holds only what its unwinding will read: most frames (a reflective,
-                    // opaque surface) are the colour so far, one factor and the flags
-                    f_acc[sp][0] = surface.x;
-                    f_acc[sp][1] = surface.y;
-                    f_acc[sp][2] = surface.z;
+                    // opaque surface) are the colour so far and the meta word
+                    set_frame_acc(sp, surface);
                     if (flags & kSchlick) f_R[sp] = R;
                     if (has_refract) f_transp[sp] = m_transparency;
                     if (has_reflect) {
-                        f_refl[sp] = m_reflective;
                         if (has_refract) {
                             f_ray[sp][0] = under_point.x;
                             f_ray[sp][1] = under_point.y;
@@ -878,12 +922,12 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                             f_ray[sp][4] = refr_dir.y;
                             f_ray[sp][5] = refr_dir.z;
                         }
-                        f_flags[sp] = flags;
+                        set_frame_meta(sp, flags | (hit.idx << kMetaShapeShift));
                         ro = over_point;
                         rd = reflectv;
                     } else {
                         // no reflected child: its term is Color.Black and adds nothing
-                        f_flags[sp] = flags | kWaitRefract;
+                        set_frame_meta(sp, flags | kWaitRefract | (hit.idx << kMetaShapeShift));
                         ro = under_point;
                         rd = refr_dir;
                     }
@@ -908,27 +952,25 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 // below are requested before the top one is combined, so that popping several
                 // frames costs about one memory latency instead of one per field per frame.
                 int f = sp - 1;
-                int flags = f_flags[f];
-                double kr = f_refl[f], kt = f_transp[f], fR = f_R[f];
-                V3 acc0 = {f_acc[f][0], f_acc[f][1], f_acc[f][2]};
+                int flags = frame_meta(f);
+                double kr = shade_of(flags >> kMetaShapeShift).reflective, kt = f_transp[f], fR = f_R[f];
+                V3 acc0 = frame_acc(f);
                 for (;;) {
                     const int fn = f > 0 ? f - 1 : 0;
-                    const int n_flags = f_flags[fn];
-                    const double n_kr = f_refl[fn], n_kt = f_transp[fn], n_R = f_R[fn];
-                    const V3 n_acc = {f_acc[fn][0], f_acc[fn][1], f_acc[fn][2]};
+                    const int n_flags = frame_meta(fn);
+                    const double n_kr = shade_of(n_flags >> kMetaShapeShift).reflective, n_kt = f_transp[fn], n_R = f_R[fn];
+                    const V3 n_acc = frame_acc(fn);
                     if (!(flags & kWaitRefract)) {
                         // reflected child returned: color.scale(reflective) [.scale(reflectance)]
                         V3 c = {kr * ret.x, kr * ret.y, kr * ret.z};
                         if (flags & kSchlick) c = {fR * c.x, fR * c.y, fR * c.z};
                         const V3 acc = {acc0.x + c.x, acc0.y + c.y, acc0.z + c.z};
                         if (flags & kHasRefract) {
-                            f_acc[f][0] = acc.x;
-                            f_acc[f][1] = acc.y;
-                            f_acc[f][2] = acc.z;
-                            f_flags[f] = flags | kWaitRefract;
+                            set_frame_acc(f, acc);
+                            set_frame_meta(f, flags | kWaitRefract);
                             if (flags & kOutsourced) {
                                 waiting = true;
-                                wait_lane = (flags >> 8) & 63;
+                                wait_lane = (flags >> kMetaPartnerShift) & 63;
                             } else {
                                 ro = {f_ray[f][0], f_ray[f][1], f_ray[f][2]};
                                 rd = {f_ray[f][3], f_ray[f][4], f_ray[f][5]};
@@ -962,6 +1004,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     mode = kHelperDone;
                 } else {
                     // canvas.set (canvas.zig:24-28)
+#ifdef RTC_COSTMAP
+                    ret = {(double)cost_nodes, 0.0, 0.0};  // developer build: nodes traced per pixel instead of the colour
+#endif
                     g_out[out_index + 0] = ret.x;
                     g_out[out_index + 1] = ret.y;
                     g_out[out_index + 2] = ret.z;
@@ -1057,7 +1102,7 @@ hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t s
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.tab, world.shade, world.order, job.rays,
-                       job.out, job.counter, (unsigned long long*)job.stats, world, job);
+                       job.tile_order, job.out, job.counter, (unsigned long long*)job.stats, world, job);
     return hipGetLastError();
 }
 

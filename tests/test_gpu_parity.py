@@ -320,6 +320,27 @@ def test_value_identical_shapes_are_rejected():  # calc.zig:274,280 identify obj
     assert e.value.code == D.RTC_ERR_DUPLICATE_SHAPE
 
 
+def test_one_scene_many_cameras():
+    """The queue order is planned per camera from where the transparent shapes project to and is
+    cached in the scene handle: different cameras on one handle (glass in view, off to a side,
+    behind the eye, the eye inside a glass sphere, a repeated camera) must all match the oracle."""
+    w, _ = scenes.draw_world_scene(64, 32)
+    views = [  # (hsize, vsize, fov, from, to)
+        (200, 100, 1.152, (-2.6, 1.5, -3.9), (-0.6, 1, -0.8)),
+        (130, 70, 0.5, (-2.6, 1.5, -3.9), (4.0, 0.5, 1.0)),
+        (96, 128, 1.4, (-0.6, 1.5, -3.0), (-0.6, 1.5, -4.9)),
+        (90, 60, 1.2, (0.6, 0.7, -0.6), (-1.0, 0.9, 2.0)),
+        (200, 100, 1.152, (-2.6, 1.5, -3.9), (-0.6, 1, -0.8)),
+        (333, 17, 2.0, (3.0, 4.0, 3.0), (0.0, 0.0, 0.0)),
+    ]
+    with scene_of(w) as sc:
+        for hs, vs, fov, frm, to in views:
+            cam = Camera(hs, vs, fov)
+            cam.transform = view_transform(init_point(*frm), init_point(*to), init_vector(0, 1, 0))
+            got = sc.render(cam.desc(), 5)
+            assert_identical(got.reshape(vs, hs, 3), O.render(w, cam, 5, O.STREAMING), f"camera {frm}->{to} {hs}x{vs}")
+
+
 # ------------------------------------------------------------------------------- full-size properties
 def test_full_size_frame_properties():
     """3840x2160 (the headline size): sampled rows identical to the oracle, idempotent,
