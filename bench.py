@@ -71,6 +71,20 @@ def executed_flops(st, groups):
     )
 
 
+def pmc_traffic(workload, n_gpus):
+    """Memory-side bytes per render_kernel launch, from the committed PMC passes of this same
+    command (hardware counters cannot be read inside a timed run); None when no pass covers
+    the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            entry = json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+    if not entry or entry.get("n_gpus") != n_gpus:
+        return None
+    return entry["read_bytes"] + entry["write_bytes"]
+
+
 def cpu_baseline(world, camera, depth, budget_s=20.0):
     """Single-thread CPU baseline on this host: the oracle (a port of the reference) on a
     bounded sample of the same frame.  Rows are sampled with a fixed stride; the literal
@@ -176,6 +190,14 @@ def main():
         gathered = torch.empty((world_size, n_rank0), dtype=torch.float64, device=dev)
         canvas = torch.empty(hsize * vsize * 3, dtype=torch.float64, device=dev)
 
+    # second leg for N > 1: quantise on each rank (ppm.zig:6-9) and gather 3 B instead of 24 B per pixel
+    local_u8 = gathered_u8 = canvas_u8 = None
+    if world_size > 1:
+        local_u8 = torch.empty(n_rank0, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            gathered_u8 = torch.empty((world_size, n_rank0), dtype=torch.uint8, device=dev)
+            canvas_u8 = torch.empty(hsize * vsize * 3, dtype=torch.uint8, device=dev)
+
     stream = torch.cuda.current_stream().cuda_stream
 
     def gather_and_assemble():
@@ -190,6 +212,19 @@ def main():
             dist.gather(local, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
         if rank == 0:
             native.deinterleave_device(cam, world_size, n_rank0, gathered.data_ptr(), canvas.data_ptr(), stream)
+
+    def gather_and_assemble_u8():
+        native.quantize_u8_device(local.data_ptr(), n_rank0, local_u8.data_ptr(), stream)
+        if args.rehearse_on_one_gpu:
+            host = local_u8.cpu()
+            parts = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if rank == 0:
+                gathered_u8.copy_(torch.stack(parts))
+        else:
+            dist.gather(local_u8, list(gathered_u8.unbind(0)) if rank == 0 else None, dst=0)
+        if rank == 0:
+            native.deinterleave_u8_device(cam, world_size, n_rank0, gathered_u8.data_ptr(), canvas_u8.data_ptr(), stream)
 
     def step():
         scene.render_device(cam, args.depth, local.data_ptr(), rank, world_size, stream)
@@ -233,10 +268,23 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
 
-    t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    elapsed_u8 = 0.0
+    if world_size > 1:
+        # the same frames with the 8-bit gather (reported beside the headline, never as `value`)
+        scene.render_device(cam, args.depth, local.data_ptr(), rank, world_size, stream)
+        gather_and_assemble_u8()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            scene.render_device(cam, args.depth, local.data_ptr(), rank, world_size, stream)
+            gather_and_assemble_u8()
+        fence()
+        elapsed_u8 = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, kernel_ms, elapsed_u8], dtype=torch.float64, device=dev)
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max, kernel_ms_max = (float(v) for v in t.tolist())
+    elapsed_max, kernel_ms_max, elapsed_u8_max = (float(v) for v in t.tolist())
 
     if args.verify and world_size > 1 and rank == 0:
         whole = torch.empty(hsize * vsize * 3, dtype=torch.float64, device=dev)
@@ -244,7 +292,12 @@ def main():
         torch.cuda.synchronize()
         if not torch.equal(whole, canvas):
             raise SystemExit("verify FAILED: assembled canvas differs from the 1-rank render")
-        print("verify ok: assembled canvas identical to the 1-rank render", file=sys.stderr)
+        q = torch.empty(hsize * vsize * 3, dtype=torch.uint8, device=dev)
+        native.quantize_u8_device(whole.data_ptr(), hsize * vsize * 3, q.data_ptr(), stream)
+        torch.cuda.synchronize()
+        if not torch.equal(q, canvas_u8):
+            raise SystemExit("verify FAILED: assembled 8-bit canvas differs from the quantised 1-rank render")
+        print("verify ok: assembled f64 and 8-bit canvases identical to the 1-rank render", file=sys.stderr)
 
     if rank == 0:
         ms_per_step = elapsed_max * 1e3 / args.steps
@@ -284,7 +337,7 @@ def main():
                 "peak": PEAK_FP64_NO_FMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_NO_FMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload, world_size),
                 "kernel": "render_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": local_flops,
@@ -300,6 +353,10 @@ def main():
                 "axis-aligned inverses, so `frac` can exceed `frac_executed` (and 1.0 on scenes of such shapes)",
             },
         }
+        if world_size > 1:
+            ms_u8 = elapsed_u8_max * 1e3 / args.steps
+            out["config"]["frame_ms_with_u8_gather"] = ms_u8
+            out["config"]["rays_per_s_with_u8_gather"] = total["radiance_rays"] / (ms_u8 * 1e-3)
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, camera, args.depth, args.cpu_budget)
             out["config"]["speedup_vs_cpu_literal"] = rays_per_s / out["cpu_baseline"]["value"]

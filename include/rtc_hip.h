@@ -190,6 +190,15 @@ int rtc_color_at(RtcScene* scene, const double* rays, uint64_t n_rays, int32_t d
  * for n_values doubles.  Device pointers. */
 int rtc_quantize_u8_device(const void* d_rgb, uint64_t n_values, void* d_out_u8, void* hip_stream);
 
+/* rtc_deinterleave_device for quantised tile buffers: each rank quantises its dense tile buffer
+ * with rtc_quantize_u8_device (one byte per value, same order), the gather moves 3 B instead of
+ * 24 B per pixel, and this call scatters the gathered bytes (rank r's buffer at d_gathered_u8 +
+ * r*per_rank_bytes) into the row-major 8-bit canvas canvasToPPM (ppm.zig:11-38) formats.
+ * With tile_ranks == 1 the tile buffer of rtc_render_device is already the row-major canvas;
+ * this call then expects the tiled layout and is not needed. */
+int rtc_deinterleave_u8_device(const RtcCameraDesc* camera, uint32_t tile_ranks, uint64_t per_rank_bytes,
+                               const void* d_gathered_u8, void* d_out_u8, void* hip_stream);
+
 /* ---- diagnostics (used by the parity tests) ------------------------------ */
 
 /* Mat4.inverse (matrix.zig:286-300) and Mat4.determinant (matrix.zig:272-280) exactly as

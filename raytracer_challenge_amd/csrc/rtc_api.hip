@@ -720,6 +720,21 @@ int rtc_deinterleave_device(const RtcCameraDesc* camera, uint32_t tile_ranks, ui
     return RTC_OK;
 }
 
+int rtc_deinterleave_u8_device(const RtcCameraDesc* camera, uint32_t tile_ranks, uint64_t per_rank_bytes,
+                               const void* d_gathered_u8, void* d_out_u8, void* hip_stream) {
+    if (int rc = check_camera(camera)) return rc;
+    if (!d_gathered_u8 || !d_out_u8) return fail(RTC_ERR_INVALID_ARGUMENT, "device pointer is NULL");
+    if (tile_ranks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "tile_ranks must be >= 1");
+    uint64_t need = 0;
+    if (int rc = rtc_tile_buffer_doubles(camera, 0, tile_ranks, &need)) return rc;
+    if (tile_ranks > 1 && per_rank_bytes < need)
+        return fail(RTC_ERR_INVALID_ARGUMENT, "per_rank_bytes smaller than rank 0's quantised tile buffer");
+    HIP_TRY(rtc::launch_deinterleave_u8((const uint8_t*)d_gathered_u8, per_rank_bytes, tile_ranks,
+                                        (uint32_t)camera->hsize, (uint32_t)camera->vsize, (uint8_t*)d_out_u8,
+                                        (hipStream_t)hip_stream));
+    return RTC_OK;
+}
+
 int rtc_quantize_u8_device(const void* d_rgb, uint64_t n_values, void* d_out_u8, void* hip_stream) {
     if (n_values == 0) return RTC_OK;
     if (!d_rgb || !d_out_u8) return fail(RTC_ERR_INVALID_ARGUMENT, "device pointer is NULL");

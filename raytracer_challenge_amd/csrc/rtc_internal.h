@@ -73,6 +73,8 @@ struct DevJob {
 hipError_t launch_render(const DevWorld& world, const DevJob& job, bool with_stats, hipStream_t stream);
 hipError_t launch_deinterleave(const double* gathered, uint64_t per_rank_doubles, uint32_t tile_ranks,
                                uint32_t hsize, uint32_t vsize, double* out, hipStream_t stream);
+hipError_t launch_deinterleave_u8(const uint8_t* gathered, uint64_t per_rank_bytes, uint32_t tile_ranks,
+                                  uint32_t hsize, uint32_t vsize, uint8_t* out, hipStream_t stream);
 hipError_t launch_quantize(const double* rgb, uint64_t n, uint8_t* out, hipStream_t stream);
 hipError_t launch_arith_probe(const double* a, const double* b, uint64_t n, double* out_div, double* out_sqrt,
                               double* out_pow, hipStream_t stream);

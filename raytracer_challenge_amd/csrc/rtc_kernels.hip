@@ -1042,10 +1042,11 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 }
 
 // Scatter gathered per-rank tile buffers into the row-major canvas.
-__global__ __launch_bounds__(kBlock) void deinterleave_kernel(const double* __restrict__ gathered,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void deinterleave_kernel(const T* __restrict__ gathered,
                                                               uint64_t per_rank_doubles, uint32_t tile_ranks,
                                                               uint32_t hsize, uint32_t vsize, uint32_t tiles_x,
-                                                              uint32_t tiles_total, double* __restrict__ out) {
+                                                              uint32_t tiles_total, T* __restrict__ out) {
     const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
     const uint64_t total = (uint64_t)tiles_total * tile_px;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
@@ -1054,8 +1055,8 @@ __global__ __launch_bounds__(kBlock) void deinterleave_kernel(const double* __re
         const uint32_t py = (gt / tiles_x) * RTC_TILE_H + within / RTC_TILE_W;
         if (px >= hsize || py >= vsize) continue;
         const uint32_t rank = gt % tile_ranks, lt = gt / tile_ranks;
-        const double* src = gathered + (uint64_t)rank * per_rank_doubles + ((uint64_t)lt * tile_px + within) * 3;
-        double* dst = out + ((uint64_t)py * hsize + px) * 3;
+        const T* src = gathered + (uint64_t)rank * per_rank_doubles + ((uint64_t)lt * tile_px + within) * 3;
+        T* dst = out + ((uint64_t)py * hsize + px) * 3;
         dst[0] = src[0];
         dst[1] = src[1];
         dst[2] = src[2];
@@ -1129,8 +1130,10 @@ hipError_t launch_render(const DevWorld& world, const DevJob& job, bool with_sta
                 : launch_variant<kMaxDepthLarge, false, false>(world, job, stream);
 }
 
-hipError_t launch_deinterleave(const double* gathered, uint64_t per_rank_doubles, uint32_t tile_ranks, uint32_t hsize,
-                               uint32_t vsize, double* out, hipStream_t stream) {
+namespace {
+template <typename T>
+hipError_t launch_deinterleave_t(const T* gathered, uint64_t per_rank_values, uint32_t tile_ranks, uint32_t hsize,
+                                 uint32_t vsize, T* out, hipStream_t stream) {
     const uint32_t tiles_x = (hsize + RTC_TILE_W - 1) / RTC_TILE_W;
     const uint32_t tiles_y = (vsize + RTC_TILE_H - 1) / RTC_TILE_H;
     const uint32_t tiles_total = tiles_x * tiles_y;
@@ -1138,9 +1141,20 @@ hipError_t launch_deinterleave(const double* gathered, uint64_t per_rank_doubles
     uint64_t blocks = (total + kBlock - 1) / kBlock;
     if (blocks > 65536) blocks = 65536;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, gathered, per_rank_doubles,
+    hipLaunchKernelGGL(deinterleave_kernel<T>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, gathered, per_rank_values,
                        tile_ranks, hsize, vsize, tiles_x, tiles_total, out);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_deinterleave(const double* gathered, uint64_t per_rank_doubles, uint32_t tile_ranks, uint32_t hsize,
+                               uint32_t vsize, double* out, hipStream_t stream) {
+    return launch_deinterleave_t<double>(gathered, per_rank_doubles, tile_ranks, hsize, vsize, out, stream);
+}
+
+hipError_t launch_deinterleave_u8(const uint8_t* gathered, uint64_t per_rank_bytes, uint32_t tile_ranks, uint32_t hsize,
+                                  uint32_t vsize, uint8_t* out, hipStream_t stream) {
+    return launch_deinterleave_t<uint8_t>(gathered, per_rank_bytes, tile_ranks, hsize, vsize, out, stream);
 }
 
 hipError_t launch_quantize(const double* rgb, uint64_t n, uint8_t* out, hipStream_t stream) {

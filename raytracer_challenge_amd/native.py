@@ -50,6 +50,7 @@ def lib():
     L.rtc_render_device.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
     L.rtc_tile_buffer_doubles.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, C.POINTER(u64)]
     L.rtc_deinterleave_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
+    L.rtc_deinterleave_u8_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
     L.rtc_color_at.argtypes = [vp, dp, u64, i32, dp, C.POINTER(D.RtcStats)]
     L.rtc_quantize_u8_device.argtypes = [vp, u64, vp, vp]
     L.rtc_mat4_inverse.argtypes = [dp, dp, dp]
@@ -73,6 +74,7 @@ EXPORTS = (
     "rtc_render_device",
     "rtc_tile_buffer_doubles",
     "rtc_deinterleave_device",
+    "rtc_deinterleave_u8_device",
     "rtc_color_at",
     "rtc_quantize_u8_device",
     "rtc_mat4_inverse",
@@ -124,6 +126,11 @@ def tile_buffer_doubles(camera_desc, tile_rank, tile_ranks):
 
 def deinterleave_device(camera_desc, tile_ranks, per_rank_doubles, d_gathered, d_out, stream=None):
     check(lib().rtc_deinterleave_device(C.byref(camera_desc), tile_ranks, per_rank_doubles, d_gathered, d_out, stream))
+
+
+def deinterleave_u8_device(camera_desc, tile_ranks, per_rank_bytes, d_gathered_u8, d_out_u8, stream=None):
+    check(lib().rtc_deinterleave_u8_device(C.byref(camera_desc), tile_ranks, per_rank_bytes, d_gathered_u8, d_out_u8,
+                                           stream))
 
 
 def quantize_u8_device(d_rgb, n_values, d_out_u8, stream=None):

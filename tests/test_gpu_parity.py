@@ -382,6 +382,13 @@ def test_full_size_frame_properties():
         native.quantize_u8_device(full.data_ptr(), hs * vs * 3, q.data_ptr())
         torch.cuda.synchronize()
         assert np.array_equal(q.cpu().numpy().reshape(vs, hs, 3), byte_color_values(host))
+        # ... and per rank before the gather (3 B instead of 24 B per pixel on the wire)
+        gq = torch.empty((ranks, n0), dtype=torch.uint8, device=dev)
+        native.quantize_u8_device(gathered.data_ptr(), ranks * n0, gq.data_ptr())
+        q2 = torch.zeros(hs * vs * 3, dtype=torch.uint8, device=dev)
+        native.deinterleave_u8_device(cd, ranks, n0, gq.data_ptr(), q2.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(q2, q)
     rows = (7, vs, 48)
     cpu = O.render(w, c, 5, O.STREAMING, rows=rows)
     sel = slice(rows[0], rows[1], rows[2])
