@@ -105,7 +105,10 @@ typedef struct RtcCameraDesc {
  * each is one full sweep over every shape.  sphere_hits / plane_hits count the
  * (ray, shape) pairs whose local intersect produced t values (shape.zig:35,62).
  * shaded_hits counts calc.shadeHit invocations.  kernel_ms is the device time of the
- * render kernel measured with HIP events on the stream it ran on. */
+ * render kernel measured with HIP events on the stream it ran on.  sphere_bound_skips counts
+ * the (ray, sphere) pairs (part of sphere_tests) that the library dismissed with its bounding
+ * sphere test without evaluating the reference's 54-flop intersection: their discriminant
+ * would have been negative. */
 typedef struct RtcStats {
     uint64_t radiance_rays;
     uint64_t shadow_rays;
@@ -116,6 +119,7 @@ typedef struct RtcStats {
     uint64_t shaded_hits;
     uint64_t pixels;
     double kernel_ms;
+    uint64_t sphere_bound_skips;
 } RtcStats;
 
 /* Opaque handle of an uploaded world (World, world.zig:15-28). */

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -249,7 +250,7 @@ int check_camera(const RtcCameraDesc* c) {
 
 // Fill stats from the device counters (after the stream has been synchronised).
 int read_stats(RtcScene* s, RtcStats* out, uint64_t pixels, float ms) {
-    uint64_t h[5];
+    uint64_t h[6];
     HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
     out->radiance_rays = h[0];
     out->shadow_rays = h[1];
@@ -258,9 +259,57 @@ int read_stats(RtcScene* s, RtcStats* out, uint64_t pixels, float ms) {
     out->sphere_hits = h[2];
     out->plane_hits = h[3];
     out->shaded_hits = h[4];
+    out->sphere_bound_skips = h[5];
     out->pixels = pixels;
     out->kernel_ms = ms;
     return RTC_OK;
+}
+
+// Upper bound of the largest singular value of the 3x3 part of a row-major matrix with row
+// stride `stride`: exact for a diagonal matrix, else min(Frobenius, sqrt(max column sum * max
+// row sum)).
+double stretch_bound(const double* m, int stride) {
+    const double* r0 = m;
+    const double* r1 = m + stride;
+    const double* r2 = m + 2 * stride;
+    if (r0[1] == 0 && r0[2] == 0 && r1[0] == 0 && r1[2] == 0 && r2[0] == 0 && r2[1] == 0)
+        return std::fmax(std::fabs(r0[0]), std::fmax(std::fabs(r1[1]), std::fabs(r2[2])));
+    double fro = 0, n1 = 0, ninf = 0;
+    for (int a = 0; a < 3; ++a) {
+        const double* row = m + a * stride;
+        fro += row[0] * row[0] + row[1] * row[1] + row[2] * row[2];
+        ninf = std::fmax(ninf, std::fabs(row[0]) + std::fabs(row[1]) + std::fabs(row[2]));
+        n1 = std::fmax(n1, std::fabs(r0[a]) + std::fabs(r1[a]) + std::fabs(r2[a]));
+    }
+    return std::fmin(std::sqrt(fro), std::sqrt(n1 * ninf)) * (1.0 + 0x1p-40);
+}
+
+// World-space bounding sphere of a sphere shape for the sweep's early-out: out[0..2] centre,
+// out[3] squared radius plus the error margin.  The sweep skips a (ray, sphere) pair when
+//     (|c - o|^2 (1 - 2^-27) - out[3]) |d|^2 > ((c - o).d)^2 ,
+// i.e. when the line passes the bounding sphere by more than 2^-28 (|o|^2 + |c|^2 + r^2) in squared
+// distance (|o|^2 <= 2|c - o|^2 + 2|c|^2).  In exact arithmetic on the stored inverse the
+// reference's discriminant is 4|ld|^2 (1 - (distance/r')^2) < 0 there (r' <= r the extent of the
+// ellipsoid along the line's normal).  Its floating-point evaluation, the test's own rounding
+// and the difference between the forward transform's centre and the stored inverse's move that
+// squared distance by at most ~50 cond^2 2^-53 (|o|^2 + |c|^2 + r^2) with cond = stretch(transform)
+// * stretch(inverse); the margin covers cond^2 up to 2^12 with a factor 2^8 to spare, and
+// shapes beyond that (or with non-finite numbers) get no bound.
+void sphere_bound(const RtcShapeDesc& s, const double* inv12, double* out) {
+    out[0] = out[1] = out[2] = 0.0;
+    out[3] = std::numeric_limits<double>::infinity();
+    if (s.geo != RTC_GEO_SPHERE) return;
+    const double* t = s.transform;
+    const double r = stretch_bound(t, 4), rinv = stretch_bound(inv12, 4);
+    const double cond2 = (r * rinv) * (r * rinv);
+    const double cc = t[3] * t[3] + t[7] * t[7] + t[11] * t[11];
+    const double r2 = r * r * (1.0 + 0x1p-30);
+    const double bound = r2 + 0x1p-28 * (3.0 * cc + r2) * (1.0 + 0x1p-30);
+    if (!(cond2 < 4096.0) || !std::isfinite(bound) || !std::isfinite(cc)) return;
+    out[0] = t[3];
+    out[1] = t[7];
+    out[2] = t[11];
+    out[3] = bound;
 }
 
 // Largest factor by which the 3x3 part of a row-major 4x4 stretches a vector (its largest
@@ -469,7 +518,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     if (!(light->position[3] == 1.0))
         return fail(RTC_ERR_INVALID_ARGUMENT, "light.position must be a point (w == 1)");
 
-    constexpr size_t kRec = 16;  // doubles per sweep-table record, see DevWorld
+    constexpr size_t kRec = rtc::kRecordDoubles;  // doubles per sweep-table record, see DevWorld
     std::vector<double> inv12(n_shapes * 12);
     std::vector<int> group_of(n_shapes);
     std::vector<rtc::DevShade> shade(n_shapes);
@@ -552,6 +601,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 std::memcpy(&tab[pos * kRec], &inv12[i * 12], 12 * sizeof(double));
                 const int64_t order_word = (int64_t)i;
                 std::memcpy(&tab[pos * kRec + 12], &order_word, sizeof order_word);
+                sphere_bound(shapes[i], &inv12[i * 12], &tab[pos * kRec + 13]);
                 order[pos] = (int32_t)i;
                 shade_tab[pos] = shade[i];
                 ++pos;

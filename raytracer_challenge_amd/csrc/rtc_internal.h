@@ -16,6 +16,8 @@ constexpr int kMaxDepthLarge = 16;
 
 // Per-shape record read by one lane after it knows which shape it hit (a gather).
 // Everything a hit needs that the sweep table does not hold.
+constexpr int kRecordDoubles = 20;  // doubles per sweep-table record (see DevWorld)
+
 struct DevShade {
     double color[3];
     double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
@@ -32,10 +34,12 @@ struct DevShade {
 // The shapes are stored in "table order": four groups (spheres whose inverse is diagonal,
 // other spheres, planes whose inverse row 1 is (0,m,0,t), other planes), each group in the
 // reference's list order.  group[g]..group[g+1] are the table positions of group g.
-//   tab   : (n+2) x 16 doubles, one 128-byte record per shape: [0..11] rows 0..2 of
+//   tab   : (n+2) x 20 doubles, one 160-byte record per shape: [0..11] rows 0..2 of
 //           inverse(shape.transform), row-major 3x4; [12] the shape's index in the reference's
-//           list (an integer in the low bits of the word); [13..15] padding.  The sweep reads
-//           it with wave-uniform addresses, up to two records ahead, hence two padding records.
+//           list (an integer in the low bits of the word); [13..15] centre and [16] enlarged
+//           squared radius of a world-space bounding sphere (spheres only; +inf = none);
+//           [17..19] padding.  The sweep reads it with wave-uniform addresses, up to two
+//           records ahead, hence two padding records.
 //   shade : n x DevShade, table order — gathered per lane at a hit.
 //   order : n x int32, table position -> list index (tie-breaks between equal t).
 struct DevWorld {

@@ -241,13 +241,26 @@ struct Sweep {
 };
 constexpr int kExitOpenBit = 1 << 30;
 
-constexpr int kRecDoubles = 16;  // one shape record: 12 matrix entries, the list index, padding (128 B)
+constexpr int kRecDoubles = rtc::kRecordDoubles;  // one shape record: 12 matrix entries, the list index, bounding sphere
+#ifdef RTC_MUTATE_BOUND
+constexpr double kBoundShrink = 1.0 + 0x1p-20;  // test of the tests: skips too eagerly
+#else
+constexpr double kBoundShrink = 1.0 - 0x1p-27;
+#endif  // see the bounding-sphere test in sweep_shape and its host side
 constexpr double kOneMinus = 1.0 - 0x1p-40;
 constexpr double kOnePlus = 1.0 + 0x1p-40;
+
+// STATS builds only: (ray, shape) pairs whose local intersect produced roots, and pairs the
+// bounding-sphere test dismissed.
+struct SweepCounters {
+    uint32_t sphere_hits, plane_hits, sphere_skips;
+};
 
 struct ShapeRec {
     double m[12];
     long long order;  // index of the shape in the reference's list (world.objects)
+    double bc[3];     // spheres: centre of a world-space bounding sphere ...
+    double br2;       // ... and its squared radius, enlarged by the error margin (+inf: no bound)
 };
 // Wave-uniform read of the record at table position i (scalar loads); the table ends with
 // padding records so that reading ahead is always in bounds.
@@ -257,6 +270,10 @@ __device__ __forceinline__ ShapeRec load_rec(const double* __restrict__ tab, int
 #pragma unroll
     for (int k = 0; k < 12; ++k) r.m[k] = p[k];
     r.order = __double_as_longlong(p[12]);
+    r.bc[0] = p[13];
+    r.bc[1] = p[14];
+    r.bc[2] = p[15];
+    r.br2 = p[16];
     return r;
 }
 
@@ -281,8 +298,8 @@ enum : int { kSphereAxis = 0, kSphereGeneral = 1, kPlaneAxis = 2, kPlaneGeneral 
 // are equal.
 template <int KIND, bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const int* __restrict__ order_of,
-                                            const V3& o, const V3& d, Sweep& s, ContainerSlots& cs,
-                                            uint32_t& sphere_hits, uint32_t& plane_hits) {
+                                            const V3& o, const V3& d, double dd, Sweep& s, ContainerSlots& cs,
+                                            SweepCounters& ctr) {
     const double* m = rec.m;
     const int tid = (int)threadIdx.x;
     // What this shape contributes, decided inside the branches below; the sweep state itself
@@ -294,6 +311,16 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
     double push_t = 0.0;
     const bool have = SHADOW || s.idx >= 0;
     if (KIND == kSphereAxis || KIND == kSphereGeneral) {
+        // A line that passes the shape's bounding sphere by more than the error margin gives
+        // disc < 0 in the reference's arithmetic: nothing below would change any state.
+        // (distance^2 - r^2) * |d|^2 > (oc.d)^2, evaluated with fused operations: the margin
+        // folded into br2 and kBoundShrink is thousands of times their rounding error.
+        const V3 oc = {rec.bc[0] - o.x, rec.bc[1] - o.y, rec.bc[2] - o.z};
+        const double ocd = fma(oc.z, d.z, fma(oc.y, d.y, oc.x * d.x));
+        const double oc2 = fma(oc.z, oc.z, fma(oc.y, oc.y, oc.x * oc.x));
+        const double apart = fma(oc2, kBoundShrink, -rec.br2) * dd;
+        if (STATS && apart > ocd * ocd) ++ctr.sphere_skips;
+        if (!(apart > ocd * ocd)) {
         // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
         V3 lo, ld;
         if (KIND == kSphereAxis) {
@@ -311,7 +338,7 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
         const double bb = b * b;
         const double disc = bb - 4.0 * a * c;
         if (!(disc < 0)) {
-            if (STATS) ++sphere_hits;
+            if (STATS) ++ctr.sphere_hits;
             const double den = 2.0 * a;
             bool need = !(b > 0 && disc < bb * kOneMinus);
             if (have) {
@@ -334,6 +361,7 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
                 push_t = t1;
             }
         }
+        }
     } else {
         // Plane.localIntersect (shape.zig:55-70): only row 1 of the local ray is used
         double loy, ldy;
@@ -345,7 +373,7 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
             loy = ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7];
         }
         const bool hits = !(fabs(ldy) < kF64Eps);
-        if (STATS && hits) ++plane_hits;
+        if (STATS && hits) ++ctr.plane_hits;
         // sign of t = -loy/ldy from the sign of the product (a zero or underflowed product
         // goes to the exact path); beyond the best hit when |loy| > best*|ldy|*(1+2^-40)
         const double p = -loy * ldy;
@@ -387,17 +415,17 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
 // arithmetic.  The two record buffers alternate, so no register copies are needed.
 template <int KIND, bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, const int* __restrict__ order_of, int begin,
-                                            int end, const V3& o, const V3& d, Sweep& s, ContainerSlots& cs,
-                                            uint32_t& sphere_hits, uint32_t& plane_hits) {
+                                            int end, const V3& o, const V3& d, double dd, Sweep& s, ContainerSlots& cs,
+                                            SweepCounters& ctr) {
     if (begin >= end) return;
     ShapeRec A = load_rec(tab, begin);
     for (int i = begin; i < end; i += 2) {
         asm volatile("" ::"s"(A.order) : "memory");
         const ShapeRec B = load_rec(tab, i + 1);
-        sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, s, cs, sphere_hits, plane_hits);
+        sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, dd, s, cs, ctr);
         asm volatile("" ::"s"(B.order) : "memory");
         A = load_rec(tab, i + 2);
-        if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, s, cs, sphere_hits, plane_hits);
+        if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, dd, s, cs, ctr);
     }
 }
 
@@ -406,18 +434,19 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
 template <bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, const int* __restrict__ order_of,
                                             const DevWorld& w, const V3& o, const V3& d, Sweep& s, ContainerSlots& cs,
-                                            uint32_t& sphere_hits, uint32_t& plane_hits) {
+                                            SweepCounters& ctr) {
     const int tid = (int)threadIdx.x;
+    const double dd = fma(d.z, d.z, fma(d.y, d.y, d.x * d.x));  // for the bounding-sphere tests
     s.idx = -1;
     if (!SHADOW) {
         s.t = 0.0;
         cs.i[0][tid] = -1;
         cs.i[1][tid] = -1;
     }
-    sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, s, cs, sphere_hits, plane_hits);
-    sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, s, cs, sphere_hits, plane_hits);
-    sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, s, cs, sphere_hits, plane_hits);
-    sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, s, cs, sphere_hits, plane_hits);
+    sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, dd, s, cs, ctr);
+    sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, dd, s, cs, ctr);
+    sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, s, cs, ctr);
+    sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, s, cs, ctr);
     if (!SHADOW) {
         s.top1 = cs.i[0][tid];
         s.top2 = cs.i[1][tid];
@@ -574,7 +603,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
         }
     };
 
-    uint32_t n_radiance = 0, n_shadow = 0, n_sphere_hits = 0, n_plane_hits = 0, n_shaded = 0;
+    uint32_t n_radiance = 0, n_shadow = 0, n_shaded = 0;
+    SweepCounters ctr = {0, 0, 0};
 #ifdef RTC_COSTMAP
     int cost_nodes = 0;
 #endif
@@ -783,7 +813,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
             const int remaining = base_rem - sp;
             Sweep hit;
-            sweep_world<false, STATS>(g_tab, g_order, w, ro, rd, hit, containers, n_sphere_hits, n_plane_hits);
+            sweep_world<false, STATS>(g_tab, g_order, w, ro, rd, hit, containers, ctr);
             RTC_STAMP(pc_sweep1);
 
             have_ret = true;
@@ -825,7 +855,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 Sweep sh_hit;
                 sh_hit.t = distance;
                 RTC_STAMP(pc_prep);
-                sweep_world<true, STATS>(g_tab, g_order, w, over_point, lightv, sh_hit, containers, n_sphere_hits, n_plane_hits);
+                sweep_world<true, STATS>(g_tab, g_order, w, over_point, lightv, sh_hit, containers, ctr);
                 RTC_STAMP(pc_sweep2);
                 const bool in_shadow = sh_hit.idx >= 0;
 
@@ -1032,8 +1062,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
     if (STATS) {
         // one atomic per counter per wave
-        uint32_t v[5] = {n_radiance, n_shadow, n_sphere_hits, n_plane_hits, n_shaded};
-        for (int c = 0; c < 5; ++c) {
+        uint32_t v[6] = {n_radiance, n_shadow, ctr.sphere_hits, ctr.plane_hits, n_shaded, ctr.sphere_skips};
+        for (int c = 0; c < 6; ++c) {
             unsigned long long sum = v[c];
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
             if (lane == 0) atomicAdd(&g_stats[c], sum);

@@ -92,6 +92,7 @@ class RtcStats(C.Structure):
         ("shaded_hits", C.c_uint64),
         ("pixels", C.c_uint64),
         ("kernel_ms", C.c_double),
+        ("sphere_bound_skips", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -20,7 +20,7 @@ from golden_io import GOLDEN_DIR, NAMES, Fixture
 from raytracer_challenge_amd import (Camera, Canvas, Color, Mat4, Material, Pattern, PointLight, Shape, World,
                                      byte_color_values, canvas_to_ppm, descs as D, init_glass_sphere, init_point,
                                      init_vector, native, scenes, tiles, view_transform)
-from worlds import nested_glass_world, random_world, tie_world
+from worlds import grazing_world_and_rays, nested_glass_world, random_world, tie_world
 
 pytestmark = pytest.mark.gpu
 
@@ -244,6 +244,20 @@ def test_cpp_host_program_writes_the_same_ppm(tmp_path):
 def test_random_worlds(seed):
     w, c = random_world(seed)
     assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), f"random world {seed}")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_grazing_rays_on_small_large_far_and_stretched_spheres(seed):
+    """The sweep skips a (ray, sphere) pair when the line clears a world-space bounding sphere by
+    an error margin; rays that graze the shapes within 1e-15 .. 1e-6 of their size must still
+    give the literal integrator's colours bit for bit."""
+    w, rays = grazing_world_and_rays(seed)
+    with scene_of(w) as sc:
+        got = sc.color_at(rays, 3)
+    want = O.color_at(w, rays, 3, O.LITERAL)
+    assert_identical(got, want, f"grazing rays, seed {seed}")
+    hit = np.any(want != 0, axis=1)
+    assert 0.2 < hit.mean() < 0.995  # the set straddles hit and miss
 
 
 def test_nested_glass_world():

@@ -42,11 +42,18 @@ def _worker(rank, world_size, port, hsize, vsize, q):
         local[: idx.size * 3] = torch.from_numpy(buf.reshape(-1))
         gathered = [torch.zeros(n_rank0, dtype=torch.float64) for _ in range(world_size)] if rank == 0 else None
         dist.gather(local, gathered, dst=0)
+        # the 8-bit variant: each rank quantises its tile buffer (ppm.zig:6-9) before the gather
+        local_u8 = torch.from_numpy(O.quantize_u8(local.numpy()))
+        gathered_u8 = [torch.zeros(n_rank0, dtype=torch.uint8) for _ in range(world_size)] if rank == 0 else None
+        dist.gather(local_u8, gathered_u8, dst=0)
         if rank == 0:
             g = torch.stack(gathered).numpy().reshape(world_size, -1, 3)
             canvas = tiles.deinterleave(g, hsize, vsize, world_size)
             full = O.render(world, cam, 5, O.STREAMING)
-            q.put(bool(np.array_equal(canvas, full)))
+            g8 = torch.stack(gathered_u8).numpy().reshape(world_size, -1, 3)
+            canvas_u8 = tiles.deinterleave(g8, hsize, vsize, world_size)
+            ok_u8 = canvas_u8.dtype == np.uint8 and np.array_equal(canvas_u8, O.quantize_u8(full.reshape(-1)).reshape(full.shape))
+            q.put(bool(np.array_equal(canvas, full)) and bool(ok_u8))
     finally:
         dist.destroy_process_group()
 

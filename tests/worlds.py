@@ -103,3 +103,51 @@ def tie_world():
     cam = Camera(48, 32, 0.8)
     cam.transform = view_transform(init_point(0.2, 0.5, -7), init_point(0, 0, 0), init_vector(0, 1, 0))
     return w, cam
+
+
+def grazing_world_and_rays(seed, n_rays=6000):
+    """Spheres of very different size, stretch and distance from the origin, and rays that graze
+    them: through surface points along tangent directions, displaced along the normal by
+    0, +-1e-15 ... +-1e-6 of the shape's size, starting near and far.  Whether such a line hits
+    is decided in the last bits of the reference's discriminant; the device's bounding-sphere
+    early-out must never get ahead of it."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    w = World()
+    w.light = PointLight(init_point(-20, 30, -25), Color(1, 1, 1))
+    transforms = []
+    for kind in range(10):
+        size = 10.0 ** u(-3, 3) if kind % 3 else u(0.5, 2)
+        far = 10.0 ** u(0, 5) if kind % 2 else u(0, 5)
+        c = rng.normal(size=3)
+        c = c / np.linalg.norm(c) * far
+        m = Mat4.identity()
+        if kind < 4:      # uniform scale + translation (diagonal inverse)
+            m = m.scale(size, size, size)
+        elif kind < 7:    # non-uniform scale
+            m = m.scale(size * u(0.2, 1), size * u(0.2, 1), size * u(0.2, 1))
+        else:             # rotated, sheared ellipsoid
+            m = (m.scale(size * u(0.3, 1), size * u(0.3, 1), size * u(0.3, 1)).rotate_x(u(0, 3)).rotate_z(u(0, 3))
+                 .shear(u(-0.3, 0.3), 0, 0, 0, u(-0.3, 0.3), 0))
+        m = m.translate(float(c[0]), float(c[1]), float(c[2]))
+        transforms.append((m, size))
+        w.objects.append(Shape("sphere", m, Material(color=Color(u(0.2, 1), u(0.2, 1), u(0.2, 1)), ambient=0.5,
+                                                       reflective=0.3 if kind % 4 == 0 else 0.0)))
+    rays = np.empty((n_rays, 6))
+    for k in range(n_rays):
+        m, size = transforms[k % len(transforms)]
+        a = np.array(m.mat, dtype=np.float64).reshape(4, 4)
+        p_local = rng.normal(size=3)
+        p_local /= np.linalg.norm(p_local)
+        p = a[:3, :3] @ p_local + a[:3, 3]
+        n = np.linalg.inv(a[:3, :3]).T @ p_local   # surface normal in world space
+        n /= np.linalg.norm(n)
+        t = np.cross(n, rng.normal(size=3))
+        t /= np.linalg.norm(t)
+        eps = (0.0, 1e-15, -1e-15, 1e-13, -1e-13, 1e-11, -1e-11, 1e-9, -1e-9, 1e-6, -1e-6)[int(rng.integers(0, 11))]
+        back = size * 10.0 ** u(-1, 3)
+        o = p + n * (eps * size) - t * back
+        d = t * (1.0 if k % 2 else 10.0 ** u(-2, 2))   # refracted rays are not normalised either
+        rays[k, :3] = o
+        rays[k, 3:] = d
+    return w, rays
