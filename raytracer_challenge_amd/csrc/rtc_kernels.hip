@@ -977,55 +977,51 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
         // ---- unwind finished subtrees in the reference's post-order -----------------------
         if (have_ret) {
             bool settled = false;  // the lane descended into a child or waits for a helper
-            if (sp > 0) {
-                // The fields of the top frame are loaded in one batch, and those of the frame
-                // below are requested before the top one is combined, so that popping several
-                // frames costs about one memory latency instead of one per field per frame.
-                int f = sp - 1;
-                int flags = frame_meta(f);
-                double kr = shade_of(flags >> kMetaShapeShift).reflective, kt = f_transp[f], fR = f_R[f];
-                V3 acc0 = frame_acc(f);
-                for (;;) {
-                    const int fn = f > 0 ? f - 1 : 0;
-                    const int n_flags = frame_meta(fn);
-                    const double n_kr = shade_of(n_flags >> kMetaShapeShift).reflective, n_kt = f_transp[fn], n_R = f_R[fn];
-                    const V3 n_acc = frame_acc(fn);
+            // One pass over the levels from the deepest to the root instead of a loop over the
+            // lane's own frames: a lane pops level L when that is its top frame, so every lane is
+            // served whatever its depth, the level is a compile-time constant (LDS or private
+            // memory is decided statically, addresses are fixed) and the frames of different
+            // levels can be fetched independently of the running colour.
+#pragma unroll
+            for (int L = MAXD - 1; L >= 0; --L) {
+                if (!settled && sp == L + 1) {
+                    const int flags = frame_meta(L);
+                    const V3 acc0 = frame_acc(L);
                     if (!(flags & kWaitRefract)) {
                         // reflected child returned: color.scale(reflective) [.scale(reflectance)]
+                        const double kr = shade_of(flags >> kMetaShapeShift).reflective;
                         V3 c = {kr * ret.x, kr * ret.y, kr * ret.z};
-                        if (flags & kSchlick) c = {fR * c.x, fR * c.y, fR * c.z};
+                        if (flags & kSchlick) {
+                            const double fR = f_R[L];
+                            c = {fR * c.x, fR * c.y, fR * c.z};
+                        }
                         const V3 acc = {acc0.x + c.x, acc0.y + c.y, acc0.z + c.z};
                         if (flags & kHasRefract) {
-                            set_frame_acc(f, acc);
-                            set_frame_meta(f, flags | kWaitRefract);
+                            set_frame_acc(L, acc);
+                            set_frame_meta(L, flags | kWaitRefract);
                             if (flags & kOutsourced) {
                                 waiting = true;
                                 wait_lane = (flags >> kMetaPartnerShift) & 63;
                             } else {
-                                ro = {f_ray[f][0], f_ray[f][1], f_ray[f][2]};
-                                rd = {f_ray[f][3], f_ray[f][4], f_ray[f][5]};
+                                ro = {f_ray[L][0], f_ray[L][1], f_ray[L][2]};
+                                rd = {f_ray[L][3], f_ray[L][4], f_ray[L][5]};
                             }
                             settled = true;
-                            break;
+                        } else {
+                            ret = acc;  // + Black refracted term
+                            sp = L;
                         }
-                        ret = acc;  // + Black refracted term
                     } else {
                         // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
+                        const double kt = f_transp[L];
                         V3 c = {kt * ret.x, kt * ret.y, kt * ret.z};
                         if (flags & kSchlick) {
-                            const double T = 1.0 - fR;
+                            const double T = 1.0 - f_R[L];
                             c = {T * c.x, T * c.y, T * c.z};
                         }
                         ret = {acc0.x + c.x, acc0.y + c.y, acc0.z + c.z};
+                        sp = L;
                     }
-                    --sp;
-                    if (sp == 0) break;
-                    f = fn;
-                    flags = n_flags;
-                    kr = n_kr;
-                    kt = n_kt;
-                    fR = n_R;
-                    acc0 = n_acc;
                 }
             }
             if (!settled) {
