@@ -195,6 +195,8 @@ struct RtcScene {
     std::vector<Costly> costly;
     bool costly_everywhere = false;  // a transparent plane: no useful bound
     // the plan of the last camera / partition, reused while they do not change
+    double* d_canvas = nullptr;  // device canvas of rtc_render, kept between calls
+    size_t canvas_bytes = 0;
     uint32_t* d_tile_order = nullptr;
     uint64_t tile_order_capacity = 0;
     bool plan_valid = false, plan_identity = true;
@@ -211,6 +213,7 @@ void free_scene(RtcScene* s) {
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+    if (s->d_canvas) (void)hipFree(s->d_canvas);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     delete s;
@@ -418,6 +421,7 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
     if (s->tile_order_capacity < local_tiles) {
         s->plan_valid = false;
         if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+    if (s->d_canvas) (void)hipFree(s->d_canvas);
         s->d_tile_order = nullptr;
         s->tile_order_capacity = 0;
         HIP_TRY(hipMalloc((void**)&s->d_tile_order, local_tiles * sizeof(uint32_t)));
@@ -708,14 +712,20 @@ int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, doub
     if (!out_rgb) return fail(RTC_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
     if (int rc = check_camera(camera)) return rc;
     const size_t bytes = (size_t)camera->hsize * camera->vsize * 3 * sizeof(double);
-    double* d_out = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_out, bytes));
+    // the device-side canvas is kept with the scene and reused by later calls of the same size
+    if (scene->canvas_bytes < bytes) {
+        if (scene->d_canvas) (void)hipFree(scene->d_canvas);
+        scene->d_canvas = nullptr;
+        scene->canvas_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&scene->d_canvas, bytes));
+        scene->canvas_bytes = bytes;
+    }
+    double* d_out = scene->d_canvas;
     int rc = rtc_render_device(scene, camera, depth, 0, 1, d_out, nullptr, stats);
     if (rc == RTC_OK) {
         hipError_t e = hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail_hip("hipMemcpy(out_rgb)", e);
     }
-    (void)hipFree(d_out);
     return rc;
 }
 
