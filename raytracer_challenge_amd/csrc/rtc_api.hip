@@ -421,7 +421,6 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
     if (s->tile_order_capacity < local_tiles) {
         s->plan_valid = false;
         if (s->d_tile_order) (void)hipFree(s->d_tile_order);
-    if (s->d_canvas) (void)hipFree(s->d_canvas);
         s->d_tile_order = nullptr;
         s->tile_order_capacity = 0;
         HIP_TRY(hipMalloc((void**)&s->d_tile_order, local_tiles * sizeof(uint32_t)));
