@@ -67,6 +67,16 @@ def test_device_division_sqrt_pow_are_bit_exact():
     _, _, p = native.arith_probe(x, y)
     ref = np.array([O.zig_pow(u, v) for u, v in zip(x, y)])
     assert_identical(p.view(np.uint64), ref.view(np.uint64), "pow (integer exponents)")
+    # across the guard of the plain-multiplication path: magnitudes whose powers stay normal,
+    # turn subnormal, underflow and overflow; negative bases; exponents up to and past 1024
+    x = np.concatenate([np.exp(rng.uniform(-40, 40, 40000)) * rng.choice([1.0, -1.0], 40000),
+                        np.exp(rng.uniform(-700, 700, 4000)), 1 - np.exp(rng.uniform(-36, 0, 4000))])
+    y = np.concatenate([rng.choice([2.0, 3.0, 5.0, 7.0, 10.0, 50.0, 200.0, 300.0, 511.0, 1023.0, 1024.0, 1025.0, 4096.0],
+                                   40000),
+                        rng.choice([2.0, 5.0], 4000), rng.choice([5.0, 200.0, 300.0], 4000)])
+    _, _, p = native.arith_probe(x, y)
+    ref = np.array([O.zig_pow(u, v) for u, v in zip(x, y)])
+    assert_identical(p.view(np.uint64), ref.view(np.uint64), "pow (integer exponents, wide range)")
     x = rng.uniform(1e-6, 1, 4000)
     y = rng.choice([10.5, 2.25, 0.5, 12.5, 7.75, 0.3], 4000)
     _, _, p = native.arith_probe(x, y)
