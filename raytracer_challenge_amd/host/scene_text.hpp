@@ -1,0 +1,209 @@
+// Reader of the line-based scene format (see scenes/draw_world.scene and
+// raytracer_challenge_amd/scene_text.py, which reads the same format): worlds for the render path
+// without the reference's scene-construction code (draw_world.zig:29-192 builds its world in
+// Zig).  Transform chains are applied left to right with the fluent builders of rtc_host.hpp
+// (each op pre-multiplies, matrix.zig:116-180); numbers go through strtod (correctly rounded,
+// as Zig parses its literals).
+#pragma once
+
+#include <cstdlib>
+#include <istream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rtc_host.hpp"
+
+namespace rtc_host {
+
+struct SceneTextError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+struct Scene {
+    World world;
+    Camera camera = Camera::init(1, 1, 1.0);
+};
+
+namespace scene_text_detail {
+
+inline double number(const std::string& s) {
+    char* end = nullptr;
+    const double v = std::strtod(s.c_str(), &end);
+    if (s.empty() || end != s.c_str() + s.size()) throw SceneTextError("not a number: '" + s + "'");
+    return v;
+}
+
+inline std::vector<double> numbers(const std::string& s, size_t n, const std::string& what) {
+    std::vector<double> v;
+    std::string item;
+    std::stringstream ss(s);
+    while (std::getline(ss, item, ',')) v.push_back(number(item));
+    if (v.size() != n) throw SceneTextError(what + ": expected " + std::to_string(n) + " comma-separated numbers");
+    return v;
+}
+
+inline Mat4 parseOps(const std::string& text) {
+    Mat4 m = Mat4::identity();
+    size_t pos = 0;
+    while (pos < text.size()) {
+        if (text[pos] == '.') ++pos;
+        const size_t open = text.find('(', pos), close = text.find(')', pos);
+        if (open == std::string::npos || close == std::string::npos || close < open)
+            throw SceneTextError("malformed transform '" + text + "'");
+        const std::string name = text.substr(pos, open - pos), args = text.substr(open + 1, close - open - 1);
+        if (name == "translate") {
+            const auto v = numbers(args, 3, name);
+            m = m.translate(v[0], v[1], v[2]);
+        } else if (name == "scale") {
+            const auto v = numbers(args, 3, name);
+            m = m.scale(v[0], v[1], v[2]);
+        } else if (name == "rotate_x") {
+            m = m.rotateX(numbers(args, 1, name)[0]);
+        } else if (name == "rotate_y") {
+            m = m.rotateY(numbers(args, 1, name)[0]);
+        } else if (name == "rotate_z") {
+            m = m.rotateZ(numbers(args, 1, name)[0]);
+        } else if (name == "shear") {
+            const auto v = numbers(args, 6, name);
+            m = m.shear(v[0], v[1], v[2], v[3], v[4], v[5]);
+        } else if (name == "matrix") {
+            const auto v = numbers(args, 16, name);
+            Mat4 x{};
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) x.mat[r][c] = v[r * 4 + c];
+            m = x.mult(m);
+        } else {
+            throw SceneTextError("unknown transform op '" + name + "'");
+        }
+        pos = close + 1;
+    }
+    return m;
+}
+
+inline Color color(const std::string& s, const std::string& what) {
+    const auto v = numbers(s, 3, what);
+    return Color::init(v[0], v[1], v[2]);
+}
+
+inline Pattern::Kind patternKind(const std::string& s) {
+    if (s == "point") return Pattern::point;
+    if (s == "stripe") return Pattern::stripe;
+    if (s == "gradient") return Pattern::gradient;
+    if (s == "ring") return Pattern::ring;
+    if (s == "checkers") return Pattern::checkers;
+    throw SceneTextError("unknown pattern kind '" + s + "'");
+}
+
+}  // namespace scene_text_detail
+
+// hsize/vsize != 0 override the file's canvas size (Camera.init's aspect rule does the rest).
+inline Scene parseScene(std::istream& in, size_t hsize = 0, size_t vsize = 0) {
+    using namespace scene_text_detail;
+    Scene scene;
+    std::map<std::string, Material> materials;
+    bool have_camera = false, have_light = false, have_view = false;
+    size_t file_h = 0, file_v = 0;
+    double fov = 0, view[9] = {0};
+    std::string raw;
+    for (size_t no = 1; std::getline(in, raw); ++no) {
+        try {
+            std::stringstream line(raw.substr(0, raw.find('#')));
+            std::vector<std::string> tok;
+            for (std::string t; line >> t;) tok.push_back(t);
+            if (tok.empty()) continue;
+            const std::string head = tok[0];
+            if (head == "camera") {
+                if (tok.size() != 4) throw SceneTextError("camera takes hsize vsize field_of_view");
+                file_h = (size_t)number(tok[1]);
+                file_v = (size_t)number(tok[2]);
+                fov = number(tok[3]);
+                have_camera = true;
+            } else if (head == "view") {
+                if (tok.size() != 10) throw SceneTextError("view takes 9 numbers");
+                for (int k = 0; k < 9; ++k) view[k] = number(tok[k + 1]);
+                have_view = true;
+            } else if (head == "light") {
+                if (tok.size() != 7) throw SceneTextError("light takes 6 numbers");
+                scene.world.light = {initPoint(number(tok[1]), number(tok[2]), number(tok[3])),
+                                     Color::init(number(tok[4]), number(tok[5]), number(tok[6]))};
+                have_light = true;
+            } else if (head == "material" || head == "sphere" || head == "plane") {
+                size_t first = 1;
+                std::string name;
+                if (head == "material") {
+                    if (tok.size() < 2) throw SceneTextError("material needs a name");
+                    name = tok[1];
+                    first = 2;
+                }
+                std::map<std::string, std::string> kv;
+                for (size_t k = first; k < tok.size(); ++k) {
+                    const size_t eq = tok[k].find('=');
+                    if (eq == std::string::npos) throw SceneTextError("expected key=value, got '" + tok[k] + "'");
+                    kv[tok[k].substr(0, eq)] = tok[k].substr(eq + 1);
+                }
+                auto take = [&](const char* key, std::string* out) {
+                    auto it = kv.find(key);
+                    if (it == kv.end()) return false;
+                    *out = it->second;
+                    kv.erase(it);
+                    return true;
+                };
+                Material mat;
+                std::string v;
+                if (take("material", &v)) {
+                    auto it = materials.find(v);
+                    if (it == materials.end()) throw SceneTextError("unknown material '" + v + "'");
+                    mat = it->second;
+                }
+                Mat4 transform = Mat4::identity();
+                if (take("transform", &v)) transform = parseOps(v);
+                if (take("color", &v)) mat.color = color(v, "color");
+                if (take("ambient", &v)) mat.ambient = number(v);
+                if (take("diffuse", &v)) mat.diffuse = number(v);
+                if (take("specular", &v)) mat.specular = number(v);
+                if (take("shininess", &v)) mat.shininess = number(v);
+                if (take("reflective", &v)) mat.reflective = number(v);
+                if (take("transparency", &v)) mat.transparency = number(v);
+                if (take("refractive_index", &v)) mat.refractive_index = number(v);
+                std::string pa, pb, pt;
+                const bool has_a = take("pattern_a", &pa), has_b = take("pattern_b", &pb),
+                           has_t = take("pattern_transform", &pt);
+                if (take("pattern", &v)) {
+                    Pattern p;
+                    p.kind = patternKind(v);
+                    if (has_a) p.a = color(pa, "pattern_a");
+                    if (has_b) p.b = color(pb, "pattern_b");
+                    if (has_t) p.transform = parseOps(pt);
+                    mat.pattern = p;
+                } else if (has_a || has_b || has_t) {
+                    throw SceneTextError("pattern_a / pattern_b / pattern_transform without pattern=");
+                }
+                if (!kv.empty()) throw SceneTextError("unknown key '" + kv.begin()->first + "'");
+                if (head == "material") {
+                    materials[name] = mat;
+                } else {
+                    Shape s;
+                    s.geo = head == "plane" ? Shape::plane : Shape::sphere;
+                    s.transform = transform;
+                    s.material = mat;
+                    scene.world.objects.push_back(s);
+                }
+            } else {
+                throw SceneTextError("unknown directive '" + head + "'");
+            }
+        } catch (const SceneTextError& e) {
+            throw SceneTextError("line " + std::to_string(no) + ": " + e.what());
+        }
+    }
+    if (!have_camera || !have_light) throw SceneTextError("a scene needs a camera and a light");
+    scene.camera = Camera::init(hsize ? hsize : file_h, vsize ? vsize : file_v, fov);
+    if (have_view)  // like draw_world.zig:36-39 the three are built with initVector; only differences are used
+        scene.camera.transform = viewTransform(initVector(view[0], view[1], view[2]), initVector(view[3], view[4], view[5]),
+                                               initVector(view[6], view[7], view[8]));
+    return scene;
+}
+
+}  // namespace rtc_host

@@ -250,6 +250,41 @@ def test_cpp_host_program_writes_the_same_ppm(tmp_path):
     canvas_to_ppm(Canvas(300, 150, O.render(w, c, 5, O.STREAMING)), b)
     assert out.read_text() == b.getvalue()
 
+def test_cpp_scene_loader_and_draw_scene_tool(tmp_path):
+    """host/draw_scene reads the line-based scene format in C++ (host/scene_text.hpp): the shipped
+    Ch. 11 scene file and a random world dumped by the Python side must both give the oracle's
+    P3 file byte for byte."""
+    from raytracer_challenge_amd import scene_text
+
+    host_dir = os.path.join(os.path.dirname(native.lib_path()), "host")
+    exe = os.path.join(host_dir, "draw_scene")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", host_dir], check=True, capture_output=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "a.ppm"
+    r = subprocess.run([exe, os.path.join(root, "scenes", "draw_world.scene"), str(out), "240", "135"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    w, c = scenes.draw_world_scene(240, 135)
+    b = io.StringIO()
+    canvas_to_ppm(Canvas(240, 135, O.render(w, c, 5, O.STREAMING)), b)
+    assert out.read_text() == b.getvalue()
+
+    w, c = random_world(4)
+    c.transform = Mat4.identity()
+    scene_file = tmp_path / "random.scene"
+    scene_file.write_text(scene_text.dumps(w, c))
+    out = tmp_path / "b.ppm"
+    r = subprocess.run([exe, str(scene_file), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    b = io.StringIO()
+    canvas_to_ppm(Canvas(c.hsize, c.vsize, O.render(w, c, 5, O.LITERAL)), b)
+    assert out.read_text() == b.getvalue()
+    # malformed input is reported, not rendered
+    scene_file.write_text("camera 10 10 1.0\nlight 0 0 0 1 1 1\nsphere transform=spin(1)\n")
+    r = subprocess.run([exe, str(scene_file), str(out)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "unknown transform op" in r.stderr
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_worlds(seed):
     w, c = random_world(seed)
