@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--accel", action="store_true",
+                    help="sweep the spheres through the optional hierarchy (rtc_scene_set_acceleration); the default is "
+                    "the reference's list walk, which the roofline accounting describes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     # developer switches to rehearse the N > 1 path on a box with one GPU: every rank uses GPU 0
@@ -186,6 +189,8 @@ def main():
         world, camera = scenes.synthetic_scene(hsize, vsize)
     cam = camera.desc()
     scene = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
+    if args.accel:
+        scene.set_acceleration(D.RTC_ACCEL_BVH)
 
     n_local = native.tile_buffer_doubles(cam, rank, world_size)
     n_rank0 = native.tile_buffer_doubles(cam, 0, world_size)  # the largest tile buffer
@@ -335,6 +340,8 @@ def main():
                 "shadow_rays_per_frame": total["shadow_rays"],
                 "all_rays_per_s": (total["radiance_rays"] + total["shadow_rays"]) / (ms_per_step * 1e-3),
                 "frame_ms": ms_per_step,
+                "sweep": "hierarchy over the spheres (optional mode; flop figures below assume the list walk)"
+                if args.accel else "every shape against every ray (calc.zig:204-209)",
                 "render_kernel_ms_max_over_ranks": kernel_ms_max,
             },
             "roofline": {

@@ -144,6 +144,18 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                      RtcScene** out_scene);
 int rtc_scene_destroy(RtcScene* scene);
 
+/* Optional acceleration of the sweeps.  RTC_ACCEL_NONE (the default) tests every shape against
+ * every ray, as calc.intersectWorld does (calc.zig:204-209).  RTC_ACCEL_BVH builds a bounding
+ * volume hierarchy over the spheres (planes are always tested) and visits only the spheres whose
+ * enlarged bounding boxes the ray crosses between its origin and the best hit so far (for a
+ * shadow ray: the light); the pairs left out are ones whose intersection the reference would
+ * compute and then not use (no roots, roots behind the origin, or beyond the hit), and ties
+ * between equal t are still resolved by list order, so the canvas is the same.  With the
+ * hierarchy on, sphere_hits and sphere_bound_skips of RtcStats count visited pairs only. */
+#define RTC_ACCEL_NONE 0
+#define RTC_ACCEL_BVH 1
+int rtc_scene_set_acceleration(RtcScene* scene, int32_t mode);
+
 /* How many shapes of the scene fall in each group of the sweep table: out[0] spheres whose
  * inverse transform is diagonal (3x3 part), out[1] other spheres, out[2] planes whose inverse
  * has row 1 = (0, m, 0, t), out[3] other planes.  The groups with exact zero entries skip the

@@ -195,6 +195,15 @@ struct RtcScene {
     std::vector<Costly> costly;
     bool costly_everywhere = false;  // a transparent plane: no useful bound
     // the plan of the last camera / partition, reused while they do not change
+    // optional hierarchy over the spheres (rtc_scene_set_acceleration)
+    struct SphereBox {
+        double lo[3], hi[3];
+        int32_t pos;  // table position
+    };
+    std::vector<SphereBox> sphere_boxes;  // kept from rtc_scene_create
+    rtc::BvhNode* d_bvh = nullptr;
+    int32_t bvh_root = 0;
+    double bvh_origin_limit = 0;
     double* d_canvas = nullptr;  // device canvas of rtc_render, kept between calls
     size_t canvas_bytes = 0;
     uint32_t* d_tile_order = nullptr;
@@ -214,6 +223,7 @@ void free_scene(RtcScene* s) {
     if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->d_tile_order) (void)hipFree(s->d_tile_order);
     if (s->d_canvas) (void)hipFree(s->d_canvas);
+    if (s->d_bvh) (void)hipFree(s->d_bvh);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     delete s;
@@ -226,6 +236,9 @@ rtc::DevWorld dev_world(const RtcScene* s) {
     std::memcpy(w.group, s->group, sizeof w.group);
     w.shade = s->d_shade;
     w.n = (int32_t)s->n;
+    w.bvh = s->d_bvh;
+    w.bvh_root = s->bvh_root;
+    w.bvh_origin_limit = s->bvh_origin_limit;
     for (int i = 0; i < 3; ++i) {
         w.light_pos[i] = s->light_pos[i];
         w.light_int[i] = s->light_int[i];
@@ -313,6 +326,70 @@ void sphere_bound(const RtcShapeDesc& s, const double* inv12, double* out) {
     out[1] = t[7];
     out[2] = t[11];
     out[3] = bound;
+}
+
+// Box around the enlarged bounding sphere of sphere_bound (centre b[0..2], squared radius b[3]):
+// a line that misses the box misses that sphere, and the sweep would dismiss the pair anyway.
+// The box is grown once more, by 2^-20 of its size and position, which is far more than the
+// rounding of the slab test that is run against it.  An unbounded sphere gets an infinite box.
+RtcScene::SphereBox sphere_box(const double* b, int32_t pos) {
+    RtcScene::SphereBox box;
+    box.pos = pos;
+    const double r = std::sqrt(b[3]);
+    for (int a = 0; a < 3; ++a) {
+        const double pad = std::isfinite(r) ? r + 0x1p-20 * (r + std::fabs(b[a])) : r;
+        box.lo[a] = b[a] - pad;
+        box.hi[a] = b[a] + pad;
+    }
+    return box;
+}
+
+// Balanced hierarchy by median split along the widest axis of the centres; returns the child
+// code of the subtree over items[begin, end).
+int32_t build_bvh(std::vector<RtcScene::SphereBox>& items, size_t begin, size_t end, std::vector<rtc::BvhNode>& nodes,
+                  double lo[3], double hi[3]) {
+    if (end - begin == 1) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = items[begin].lo[a];
+            hi[a] = items[begin].hi[a];
+        }
+        return ~items[begin].pos;
+    }
+    double cmin[3] = {1e300, 1e300, 1e300}, cmax[3] = {-1e300, -1e300, -1e300};
+    for (size_t k = begin; k < end; ++k)
+        for (int a = 0; a < 3; ++a) {
+            const double c = 0.5 * items[k].lo[a] + 0.5 * items[k].hi[a];
+            if (c < cmin[a]) cmin[a] = c;
+            if (c > cmax[a]) cmax[a] = c;
+        }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+    const size_t mid = begin + (end - begin) / 2;
+    std::nth_element(items.begin() + begin, items.begin() + mid, items.begin() + end,
+                     [axis](const RtcScene::SphereBox& x, const RtcScene::SphereBox& y) {
+                         const double cx = 0.5 * x.lo[axis] + 0.5 * x.hi[axis], cy = 0.5 * y.lo[axis] + 0.5 * y.hi[axis];
+                         return cx < cy || (cx == cy && x.pos < y.pos);
+                     });
+    const size_t index = nodes.size();
+    nodes.emplace_back();
+    double l[2][3], h[2][3];
+    const int32_t c0 = build_bvh(items, begin, mid, nodes, l[0], h[0]);
+    const int32_t c1 = build_bvh(items, mid, end, nodes, l[1], h[1]);
+    rtc::BvhNode& n = nodes[index];
+    std::memset(&n, 0, sizeof n);
+    n.child[0] = c0;
+    n.child[1] = c1;
+    for (int k = 0; k < 2; ++k)
+        for (int a = 0; a < 3; ++a) {
+            n.lo[k][a] = l[k][a];
+            n.hi[k][a] = h[k][a];
+        }
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = std::fmin(l[0][a], l[1][a]);
+        hi[a] = std::fmax(h[0][a], h[1][a]);
+    }
+    return (int32_t)index;
 }
 
 // Largest factor by which the 3x3 part of a row-major 4x4 stretches a vector (its largest
@@ -590,6 +667,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         }
     }
 
+    std::vector<RtcScene::SphereBox> boxes;
     // table order: the four groups one after the other, each in list order
     std::vector<double> tab((n_shapes + 2) * kRec, 0.0);
     std::vector<int32_t> order(n_shapes ? n_shapes : 1, 0);
@@ -605,6 +683,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 const int64_t order_word = (int64_t)i;
                 std::memcpy(&tab[pos * kRec + 12], &order_word, sizeof order_word);
                 sphere_bound(shapes[i], &inv12[i * 12], &tab[pos * kRec + 13]);
+                if (shapes[i].geo == RTC_GEO_SPHERE) boxes.push_back(sphere_box(&tab[pos * kRec + 13], (int32_t)pos));
                 order[pos] = (int32_t)i;
                 shade_tab[pos] = shade[i];
                 ++pos;
@@ -631,6 +710,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         const double* t = s.transform;
         sc->costly.push_back({{t[3], t[7], t[11]}, largest_stretch(t)});
     }
+    sc->sphere_boxes = std::move(boxes);
     sc->n = n_shapes;
     sc->n_spheres = n_spheres;
     sc->n_planes = n_planes;
@@ -666,6 +746,34 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
 
 int rtc_scene_destroy(RtcScene* scene) {
     free_scene(scene);
+    return RTC_OK;
+}
+
+int rtc_scene_set_acceleration(RtcScene* scene, int32_t mode) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (mode != RTC_ACCEL_NONE && mode != RTC_ACCEL_BVH) return fail(RTC_ERR_INVALID_ARGUMENT, "unknown acceleration mode");
+    HIP_TRY(hipDeviceSynchronize());  // a launch may still be reading the hierarchy
+    if (scene->d_bvh) (void)hipFree(scene->d_bvh);
+    scene->d_bvh = nullptr;
+    if (mode == RTC_ACCEL_NONE || scene->sphere_boxes.size() < 2) return RTC_OK;
+    std::vector<RtcScene::SphereBox> items = scene->sphere_boxes;
+    std::vector<rtc::BvhNode> nodes;
+    nodes.reserve(items.size());
+    double lo[3], hi[3];
+    scene->bvh_root = build_bvh(items, 0, items.size(), nodes, lo, hi);
+    // Beyond this distance from the origin the rounding of a ray's own coordinates approaches the
+    // 2^-20 by which the boxes were grown; such rays are traced without pruning.
+    double extent = 1.0;
+    for (int a = 0; a < 3; ++a)
+        if (std::isfinite(lo[a]) && std::isfinite(hi[a])) extent = std::fmax(extent, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+    scene->bvh_origin_limit = extent * 0x1p20;
+    HIP_TRY(hipMalloc((void**)&scene->d_bvh, nodes.size() * sizeof(rtc::BvhNode)));
+    hipError_t e = hipMemcpy(scene->d_bvh, nodes.data(), nodes.size() * sizeof(rtc::BvhNode), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(scene->d_bvh);
+        scene->d_bvh = nullptr;
+        return fail_hip("hipMemcpy(bvh)", e);
+    }
     return RTC_OK;
 }
 

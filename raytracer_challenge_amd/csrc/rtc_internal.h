@@ -42,12 +42,27 @@ struct DevShade {
 //           records ahead, hence two padding records.
 //   shade : n x DevShade, table order — gathered per lane at a hit.
 //   order : n x int32, table position -> list index (tie-breaks between equal t).
+// Node of the optional bounding-volume hierarchy over the spheres (128 B): the boxes of both
+// children, so that one fetch decides both.  A child code >= 0 is a node index, < 0 is a leaf
+// holding the sphere at table position ~code.
+struct BvhNode {
+    double lo[2][3];
+    double hi[2][3];
+    int32_t child[2];
+    int32_t pad[6];
+};
+static_assert(sizeof(BvhNode) == 128, "one node per 128-byte line");
+
 struct DevWorld {
     const double* tab;
     const DevShade* shade;
     const int32_t* order;
     int32_t n;
     int32_t group[5];
+    // acceleration (rtc_scene_set_acceleration): nullptr = every sphere is tested (the reference's list walk)
+    const BvhNode* bvh;
+    int32_t bvh_root;        // child code of the root
+    double bvh_origin_limit; // rays starting farther out than this (any coordinate) are not pruned
     double light_pos[3];
     double light_int[3];
 };

@@ -429,9 +429,73 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
     }
 }
 
+// The spheres through the optional hierarchy (rtc_scene_set_acceleration) instead of the two
+// sphere loops.  Each lane walks the tree with its own ray: a node carries the (enlarged) boxes
+// of both children; a child is entered when the slab test cannot rule out that the ray crosses
+// its box between the origin and the best hit so far (the light, for a shadow ray), nearer
+// child first.  What is left out are pairs the full test would compute and not use: no roots,
+// both roots behind the origin, or the nearer root beyond the hit (a sphere around the origin
+// has the origin in its box and is always reached, so the containers are complete).  The
+// order of the visits does not matter: sweep_shape resolves equal t by list index.
+constexpr int kBvhStack = 32;  // the tree is balanced: depth <= ceil(log2(2^21 spheres)) = 21
+template <bool SHADOW, bool STATS>
+__device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab, const int* __restrict__ order_of,
+                                                  const DevWorld& w, const V3& o, const V3& d, double dd, Sweep& s,
+                                                  ContainerSlots& cs, SweepCounters& ctr) {
+    const double inf = __builtin_huge_val();
+    const double lim = w.bvh_origin_limit;
+    // rays that start far outside the scene, or whose direction is degenerate, are not pruned
+    const bool prune = fabs(o.x) <= lim && fabs(o.y) <= lim && fabs(o.z) <= lim && dd > 0.0 && dd < inf;
+    const V3 inv = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};
+    int stack[kBvhStack];
+    int sp = 0;
+    int cur = w.bvh_root;
+    for (;;) {
+        if (cur < 0) {
+            const int pos = ~cur;
+            const ShapeRec rec = load_rec(tab, pos);
+            sweep_shape<kSphereGeneral, SHADOW, STATS>(rec, pos, order_of, o, d, dd, s, cs, ctr);
+            if (SHADOW && s.idx >= 0) break;  // calc.isShadowed only asks whether anything is in the way
+            if (sp == 0) break;
+            cur = stack[--sp];
+            continue;
+        }
+        const BvhNode* __restrict__ n = w.bvh + cur;
+        const double reach = (SHADOW || s.idx >= 0) ? s.t * kOnePlus : inf;
+        bool enter[2];
+        double tnear[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            // fmin/fmax drop a NaN operand (0 * inf when the origin lies on a slab of an axis the
+            // ray is parallel to): that axis then constrains nothing
+            const double x1 = (n->lo[k][0] - o.x) * inv.x, x2 = (n->hi[k][0] - o.x) * inv.x;
+            const double y1 = (n->lo[k][1] - o.y) * inv.y, y2 = (n->hi[k][1] - o.y) * inv.y;
+            const double z1 = (n->lo[k][2] - o.z) * inv.z, z2 = (n->hi[k][2] - o.z) * inv.z;
+            const double t0 = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmin(z1, z2));
+            const double t1 = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
+            const bool missed = t0 > t1 || t1 < 0.0 || t0 > reach;
+            enter[k] = !(prune && missed);
+            tnear[k] = t0;
+        }
+        const int c0 = n->child[0], c1 = n->child[1];
+        if (enter[0] && enter[1]) {
+            const bool first0 = !(tnear[1] < tnear[0]);
+            stack[sp++] = first0 ? c1 : c0;
+            cur = first0 ? c0 : c1;
+        } else if (enter[0]) {
+            cur = c0;
+        } else if (enter[1]) {
+            cur = c1;
+        } else {
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+}
+
 // SHADOW: s.t holds the distance to the light on entry and only roots in [0, s.t) are
 // accepted (calc.zig:789: hit.t < distance); containers are not tracked.
-template <bool SHADOW, bool STATS>
+template <bool SHADOW, bool STATS, bool ACCEL>
 __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, const int* __restrict__ order_of,
                                             const DevWorld& w, const V3& o, const V3& d, Sweep& s, ContainerSlots& cs,
                                             SweepCounters& ctr) {
@@ -445,8 +509,12 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     }
     sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, dd, s, cs, ctr);
     sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, dd, s, cs, ctr);
-    sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, s, cs, ctr);
-    sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, s, cs, ctr);
+    if (ACCEL) {
+        if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, s, cs, ctr);
+    } else {
+        sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, s, cs, ctr);
+        sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, s, cs, ctr);
+    }
     if (!SHADOW) {
         s.top1 = cs.i[0][tid];
         s.top2 = cs.i[1][tid];
@@ -535,7 +603,9 @@ static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
 // The read-only tables and the output are separate __restrict__ kernel arguments so that
 // the compiler can prove the wave-uniform table reads are never clobbered by the kernel's
 // own stores and keep them on the scalar path; the structs carry the remaining scalars.
-template <int MAXD, bool STATS, bool FROM_RAYS, bool LDS>
+// TABLES: 0 = per-hit tables gathered from global memory, 1 = from their LDS copy (small
+// worlds), 2 = global memory and the spheres swept through the hierarchy.
+template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
 __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const double* __restrict__ g_tab,
                                                         const DevShade* __restrict__ g_shade,
                                                         const int* __restrict__ g_order,
@@ -544,6 +614,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                                                         double* __restrict__ g_out, uint32_t* __restrict__ g_counter,
                                                         unsigned long long* __restrict__ g_stats, const DevWorld wc,
                                                         const DevJob job) {
+    constexpr bool LDS = TABLES == 1;
+    constexpr bool ACCEL = TABLES == 2;
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS> hot;
     __shared__ FrameSlots frames;
@@ -813,7 +885,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
             const int remaining = base_rem - sp;
             Sweep hit;
-            sweep_world<false, STATS>(g_tab, g_order, w, ro, rd, hit, containers, ctr);
+            sweep_world<false, STATS, ACCEL>(g_tab, g_order, w, ro, rd, hit, containers, ctr);
             RTC_STAMP(pc_sweep1);
 
             have_ret = true;
@@ -855,7 +927,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 Sweep sh_hit;
                 sh_hit.t = distance;
                 RTC_STAMP(pc_prep);
-                sweep_world<true, STATS>(g_tab, g_order, w, over_point, lightv, sh_hit, containers, ctr);
+                sweep_world<true, STATS, ACCEL>(g_tab, g_order, w, over_point, lightv, sh_hit, containers, ctr);
                 RTC_STAMP(pc_sweep2);
                 const bool in_shadow = sh_hit.idx >= 0;
 
@@ -1111,9 +1183,9 @@ __global__ __launch_bounds__(kBlock) void arith_probe_kernel(const double* __res
     }
 }
 
-template <int MAXD, bool STATS, bool FROM_RAYS, bool LDS>
+template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
 hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t stream) {
-    auto kernel = render_kernel<MAXD, STATS, FROM_RAYS, LDS>;
+    auto kernel = render_kernel<MAXD, STATS, FROM_RAYS, TABLES>;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -1135,8 +1207,9 @@ hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t s
 
 template <int MAXD, bool STATS, bool FROM_RAYS>
 hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t stream) {
-    if (world.n <= kLdsShapes) return launch_tables<MAXD, STATS, FROM_RAYS, true>(world, job, stream);
-    return launch_tables<MAXD, STATS, FROM_RAYS, false>(world, job, stream);
+    if (world.bvh) return launch_tables<MAXD, STATS, FROM_RAYS, 2>(world, job, stream);
+    if (world.n <= kLdsShapes) return launch_tables<MAXD, STATS, FROM_RAYS, 1>(world, job, stream);
+    return launch_tables<MAXD, STATS, FROM_RAYS, 0>(world, job, stream);
 }
 
 }  // namespace

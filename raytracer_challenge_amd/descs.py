@@ -23,6 +23,8 @@ RTC_PATTERN_GRADIENT = 2
 RTC_PATTERN_RING = 3
 RTC_PATTERN_CHECKERS = 4
 
+RTC_ACCEL_NONE = 0
+RTC_ACCEL_BVH = 1
 RTC_TILE_W = 64
 RTC_TILE_H = 8
 

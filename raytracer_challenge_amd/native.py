@@ -45,6 +45,7 @@ def lib():
     L.rtc_set_device.argtypes = [i32]
     L.rtc_scene_create.argtypes = [C.POINTER(D.RtcShapeDesc), u64, C.POINTER(D.RtcLightDesc), C.POINTER(vp)]
     L.rtc_scene_destroy.argtypes = [vp]
+    L.rtc_scene_set_acceleration.argtypes = [vp, i32]
     L.rtc_scene_group_counts.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
     L.rtc_render.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, dp, C.POINTER(D.RtcStats)]
     L.rtc_render_device.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
@@ -69,6 +70,7 @@ EXPORTS = (
     "rtc_set_device",
     "rtc_scene_create",
     "rtc_scene_destroy",
+    "rtc_scene_set_acceleration",
     "rtc_scene_group_counts",
     "rtc_render",
     "rtc_render_device",
@@ -160,6 +162,10 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    def set_acceleration(self, mode):
+        """rtc_scene_set_acceleration: 0 = test every shape (default), 1 = hierarchy over the spheres."""
+        check(lib().rtc_scene_set_acceleration(self._h, int(mode)))
 
     def group_counts(self):
         """rtc_scene_group_counts: (axis spheres, general spheres, axis planes, general planes)."""

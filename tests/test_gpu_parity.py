@@ -352,6 +352,49 @@ def test_synthetic_scene_small_and_full_shape_count():
     assert st.radiance_rays == so.radiance_rays and st.sphere_hits == so.sphere_hits
 
 
+# ------------------------------------------------------------------------------- hierarchy over the spheres
+def _accel_canvas(world, cam, depth=5):
+    with scene_of(world) as sc:
+        sc.set_acceleration(D.RTC_ACCEL_BVH)
+        return sc.render(cam.desc(), depth)
+
+
+def test_hierarchy_gives_the_same_canvases():
+    """rtc_scene_set_acceleration(BVH): only spheres the ray cannot use are left out, and ties are
+    still resolved by list order, so every canvas equals the literal integrator's."""
+    for seed in range(4):
+        w, c = random_world(seed, n_spheres=40, n_planes=3)
+        assert_identical(_accel_canvas(w, c), O.render(w, c, 5, O.LITERAL), f"random world {seed} (40 spheres)")
+    for name, (w, c) in (("nested glass", nested_glass_world()), ("tie world", tie_world()),
+                         ("draw_world", scenes.draw_world_scene(160, 80))):
+        assert_identical(_accel_canvas(w, c), O.render(w, c, 5, O.LITERAL), name)
+    w, c = scenes.synthetic_scene(64, 36)  # all 10 000 shapes
+    assert_identical(_accel_canvas(w, c), O.render(w, c, 5, O.STREAMING), "synthetic 10k")
+    w, c = scenes.draw_world_scene(96, 48)
+    assert_identical(_accel_canvas(w, c, 16), O.render(w, c, 16, O.STREAMING), "depth 16")
+
+
+def test_hierarchy_with_grazing_and_outlying_rays():
+    w, rays = grazing_world_and_rays(7)
+    # rays from far outside the scene (not pruned) and along the axes (infinite slab bounds)
+    far = rays[:600].copy()
+    far[:, :3] -= far[:, 3:] / np.linalg.norm(far[:, 3:], axis=1, keepdims=True) * 1e9
+    axis = np.zeros((600, 6))
+    axis[:, :3] = rays[:600, :3]
+    axis[np.arange(600), 3 + np.arange(600) % 3] = np.where(np.arange(600) % 2, 1.0, -1.0)
+    rays = np.concatenate([rays, far, axis])
+    with scene_of(w) as sc:
+        plain = sc.color_at(rays, 3)
+        sc.set_acceleration(D.RTC_ACCEL_BVH)
+        got = sc.color_at(rays, 3)
+        sc.set_acceleration(D.RTC_ACCEL_NONE)
+        again = sc.color_at(rays, 3)
+    want = O.color_at(w, rays, 3, O.LITERAL)
+    assert_identical(plain, want, "grazing rays, list walk")
+    assert_identical(got, want, "grazing rays, hierarchy")
+    assert_identical(again, want, "grazing rays, hierarchy switched off again")
+
+
 # ------------------------------------------------------------------------------- upload validation
 def test_singular_transform_is_rejected():  # matrix.zig:288 would panic
     w = scenes.default_world()
