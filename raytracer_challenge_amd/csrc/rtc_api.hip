@@ -200,7 +200,11 @@ struct RtcScene {
         double lo[3], hi[3];
         int32_t pos;  // table position
     };
-    std::vector<SphereBox> sphere_boxes;  // kept from rtc_scene_create
+    struct SphereBound {
+        double b[4];  // centre and enlarged squared radius, as in the sweep table
+        int32_t pos;
+    };
+    std::vector<SphereBound> sphere_bounds;  // kept from rtc_scene_create
     rtc::BvhNode* d_bvh = nullptr;
     int32_t bvh_root = 0;
     double bvh_origin_limit = 0;
@@ -330,14 +334,16 @@ void sphere_bound(const RtcShapeDesc& s, const double* inv12, double* out) {
 
 // Box around the enlarged bounding sphere of sphere_bound (centre b[0..2], squared radius b[3]):
 // a line that misses the box misses that sphere, and the sweep would dismiss the pair anyway.
-// The box is grown once more, by 2^-20 of its size and position, which is far more than the
-// rounding of the slab test that is run against it.  An unbounded sphere gets an infinite box.
-RtcScene::SphereBox sphere_box(const double* b, int32_t pos) {
+// The box is grown once more, by 2^-20 of its size and position and by 2^-30 of the extent of
+// the whole scene; the slab test that is run against it rounds coordinates of at most 2^10
+// extents (rays from farther out are not pruned) to 2^-53, i.e. 2^-43 extents.  An unbounded
+// sphere gets an infinite box.
+RtcScene::SphereBox sphere_box(const double* b, int32_t pos, double scene_extent) {
     RtcScene::SphereBox box;
     box.pos = pos;
     const double r = std::sqrt(b[3]);
     for (int a = 0; a < 3; ++a) {
-        const double pad = std::isfinite(r) ? r + 0x1p-20 * (r + std::fabs(b[a])) : r;
+        const double pad = std::isfinite(r) ? r + 0x1p-20 * (r + std::fabs(b[a])) + 0x1p-30 * scene_extent : r;
         box.lo[a] = b[a] - pad;
         box.hi[a] = b[a] + pad;
     }
@@ -667,7 +673,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         }
     }
 
-    std::vector<RtcScene::SphereBox> boxes;
+    std::vector<RtcScene::SphereBound> bounds;
     // table order: the four groups one after the other, each in list order
     std::vector<double> tab((n_shapes + 2) * kRec, 0.0);
     std::vector<int32_t> order(n_shapes ? n_shapes : 1, 0);
@@ -683,7 +689,12 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 const int64_t order_word = (int64_t)i;
                 std::memcpy(&tab[pos * kRec + 12], &order_word, sizeof order_word);
                 sphere_bound(shapes[i], &inv12[i * 12], &tab[pos * kRec + 13]);
-                if (shapes[i].geo == RTC_GEO_SPHERE) boxes.push_back(sphere_box(&tab[pos * kRec + 13], (int32_t)pos));
+                if (shapes[i].geo == RTC_GEO_SPHERE) {
+                    RtcScene::SphereBound sb;
+                    std::memcpy(sb.b, &tab[pos * kRec + 13], sizeof sb.b);
+                    sb.pos = (int32_t)pos;
+                    bounds.push_back(sb);
+                }
                 order[pos] = (int32_t)i;
                 shade_tab[pos] = shade[i];
                 ++pos;
@@ -710,7 +721,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         const double* t = s.transform;
         sc->costly.push_back({{t[3], t[7], t[11]}, largest_stretch(t)});
     }
-    sc->sphere_boxes = std::move(boxes);
+    sc->sphere_bounds = std::move(bounds);
     sc->n = n_shapes;
     sc->n_spheres = n_spheres;
     sc->n_planes = n_planes;
@@ -755,18 +766,22 @@ int rtc_scene_set_acceleration(RtcScene* scene, int32_t mode) {
     HIP_TRY(hipDeviceSynchronize());  // a launch may still be reading the hierarchy
     if (scene->d_bvh) (void)hipFree(scene->d_bvh);
     scene->d_bvh = nullptr;
-    if (mode == RTC_ACCEL_NONE || scene->sphere_boxes.size() < 2) return RTC_OK;
-    std::vector<RtcScene::SphereBox> items = scene->sphere_boxes;
+    if (mode == RTC_ACCEL_NONE || scene->sphere_bounds.size() < 2) return RTC_OK;
+    // extent of the scene: the largest coordinate any bounded sphere reaches
+    double extent = 1.0;
+    for (const RtcScene::SphereBound& sb : scene->sphere_bounds) {
+        const double r = std::sqrt(sb.b[3]);
+        if (!std::isfinite(r)) continue;
+        for (int a = 0; a < 3; ++a) extent = std::fmax(extent, std::fabs(sb.b[a]) + r);
+    }
+    std::vector<RtcScene::SphereBox> items;
+    items.reserve(scene->sphere_bounds.size());
+    for (const RtcScene::SphereBound& sb : scene->sphere_bounds) items.push_back(sphere_box(sb.b, sb.pos, extent));
     std::vector<rtc::BvhNode> nodes;
     nodes.reserve(items.size());
     double lo[3], hi[3];
     scene->bvh_root = build_bvh(items, 0, items.size(), nodes, lo, hi);
-    // Beyond this distance from the origin the rounding of a ray's own coordinates approaches the
-    // 2^-20 by which the boxes were grown; such rays are traced without pruning.
-    double extent = 1.0;
-    for (int a = 0; a < 3; ++a)
-        if (std::isfinite(lo[a]) && std::isfinite(hi[a])) extent = std::fmax(extent, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
-    scene->bvh_origin_limit = extent * 0x1p20;
+    scene->bvh_origin_limit = extent * 1024.0;  // see sphere_box
     HIP_TRY(hipMalloc((void**)&scene->d_bvh, nodes.size() * sizeof(rtc::BvhNode)));
     hipError_t e = hipMemcpy(scene->d_bvh, nodes.data(), nodes.size() * sizeof(rtc::BvhNode), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
