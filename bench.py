@@ -92,28 +92,33 @@ def pmc_traffic(workload, n_gpus):
 
 def cpu_baseline(world, camera, depth, budget_s=20.0):
     """Single-thread CPU baseline on this host: the oracle (a port of the reference) on a
-    bounded sample of the same frame.  Rows are sampled with a fixed stride; the literal
+    bounded sample of the same frame.  Pixels are sampled with a fixed stride; the literal
     integrator mirrors the reference's cost model (per-call inverse, heap lists, stable
     sort), the streaming one is the strong CPU baseline (hoisted inverses, running min)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from raytracer_challenge_amd import descs as D
 
-    def run(mode, stride):
+    import numpy as np
+
+    n_pixels = camera.hsize * camera.vsize
+
+    def run(mode, n_sample):
+        # every k-th pixel of the frame in row-major order, k odd so that the samples do not line up in columns
+        n_sample = int(min(max(n_sample, 16), n_pixels))
+        k = max(n_pixels // n_sample, 1) | 1
+        idx = np.arange(k // 2, n_pixels, k, dtype=np.uint64)
         st = D.RtcStats()
         t0 = time.perf_counter()
-        O.render(world, camera, depth, mode, rows=(stride // 2, camera.vsize, stride), stats=st)
+        O.render_pixels(world, camera, idx, depth, mode, stats=st)
         dt = time.perf_counter() - t0
-        return st.radiance_rays / dt, st.radiance_rays, dt, st.pixels
+        return st.radiance_rays / dt, st.radiance_rays, dt, idx.size, k
 
-    # calibrate the strides so that each leg takes a bounded time whatever the host
-    probe_rate, _, _, _ = run(O.STREAMING, max(camera.vsize // 8, 1))
-    rays_per_row = 6.4 * camera.hsize
-    s_stride = max(1, int(camera.vsize * rays_per_row / (probe_rate * budget_s * 0.25)))
-    s_rate, s_rays, s_dt, s_px = run(O.STREAMING, s_stride)
-    lit_rate_guess = s_rate / 50.0
-    l_stride = max(1, int(camera.vsize * rays_per_row / (lit_rate_guess * budget_s * 0.75)))
-    l_rate, l_rays, l_dt, l_px = run(O.LITERAL, l_stride)
+    # calibrate the sample sizes so that each leg takes a bounded time whatever the host and the scene
+    _, _, probe_dt, probe_n, _ = run(O.STREAMING, 64)
+    s_rate, s_rays, s_dt, s_px, s_k = run(O.STREAMING, probe_n * budget_s * 0.25 / max(probe_dt, 1e-6))
+    _, _, probe_dt, probe_n, _ = run(O.LITERAL, 16)
+    l_rate, l_rays, l_dt, l_px, l_k = run(O.LITERAL, probe_n * budget_s * 0.7 / max(probe_dt, 1e-6))
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -129,9 +134,9 @@ def cpu_baseline(world, camera, depth, budget_s=20.0):
         "cores": 1,
         "kind": "port",
         "variant": "literal integrator (reference cost model: per-call inverse, heap lists, stable sort)",
-        "sample": f"every {l_stride}th row of the frame: {l_px} pixels, {l_rays} radiance rays in {l_dt:.1f} s",
+        "sample": f"every {l_k}th pixel of the frame: {l_px} pixels, {l_rays} radiance rays in {l_dt:.1f} s",
         "streaming_value": s_rate,
-        "streaming_sample": f"every {s_stride}th row: {s_px} pixels, {s_rays} radiance rays in {s_dt:.1f} s",
+        "streaming_sample": f"every {s_k}th pixel: {s_px} pixels, {s_rays} radiance rays in {s_dt:.1f} s",
         "cpu_model": cpu_model,
         "host_cores_visible": os.cpu_count(),
     }
