@@ -1,7 +1,7 @@
 // Host side above the C-ABI, in C++: the reference's scene API with the same names, argument
 // meaning and defaults, so that code written against the Zig types reads the same here.
 // The reference is Zig (no Zig toolchain in the build image); in a real integration this layer
-// stays Zig and only Camera::render's body changes.
+// stays Zig and only the body of Camera.render changes.
 //
 //   Vec4 / initPoint / initVector   vector.zig:4-118        Color            color.zig:4-59
 //   Mat4 + fluent builders          matrix.zig:99-236       Pattern          pattern.zig:64-75
