@@ -556,6 +556,11 @@ int fill_camera_job(const RtcCameraDesc* camera, int32_t depth, uint32_t tile_ra
     double cam_inv[16];
     if (int rc = invert_affine(camera->transform, cam_inv, "camera", 0)) return rc;
     std::memcpy(job->cam_inv, cam_inv, 12 * sizeof(double));
+    for (int r = 0; r < 3; ++r) {
+        const double* m = cam_inv + 4 * r;  // ((m0*x + m1*y) + m2*z) + m3 at (0,0,0), not folded
+        const volatile double zero = 0.0;
+        job->cam_origin[r] = ((m[0] * zero + m[1] * zero) + m[2] * zero) + m[3];
+    }
     job->half_width = camera->half_width;
     job->half_height = camera->half_height;
     job->pixel_size = camera->pixel_size;

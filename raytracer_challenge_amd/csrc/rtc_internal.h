@@ -71,6 +71,7 @@ struct DevWorld {
 struct DevJob {
     // camera (camera.zig:20-27) with the inverse of its transform precomputed on the host
     double cam_inv[12];
+    double cam_origin[3];  // cam_inv * point(0,0,0), evaluated as matrix.zig:215-224 does
     double half_width, half_height, pixel_size;
     uint32_t hsize, vsize;
     // tile partition (see rtc_render_device in the public header)

@@ -697,6 +697,13 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     bool exhausted = false;    // wave-uniform: the global pixel queue is empty
     uint32_t loc_next = 0, loc_end = 0;  // wave-uniform: the chunk of queue positions the wave is dealing out
 
+    // wave-uniform: the 8x8 block the current draw covers
+    uint32_t blk_base = 0, blk_px0 = 0, blk_py0 = 0;
+    bool blk_valid = false;
+    long long blk_out0 = 0;
+    // inverse(camera.transform) * point(0,0,0) (camera.zig:60): the same value for every pixel,
+    // evaluated once on the host with the same expression
+    const V3 cam_origin = {job.cam_origin[0], job.cam_origin[1], job.cam_origin[2]};
     const V3 light = {w.light_pos[0], w.light_pos[1], w.light_pos[2]};
     const V3 lint = {w.light_int[0], w.light_int[1], w.light_int[2]};
 
@@ -742,6 +749,21 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 if (base >= job.total) break;
                 loc_next = base;
                 loc_end = base + chunk < job.total ? base + chunk : job.total;
+                if (!FROM_RAYS) {
+                    // where the block lies, once per draw and wave-uniform: queue position ->
+                    // (queue slot of the tile, 8x8 block of the tile) -> local tile -> global tile
+                    const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
+                    const uint32_t slot = base / tile_px, blk = (base % tile_px) / (uint32_t)kChunk;
+                    const uint32_t lt = g_tile_order ? g_tile_order[slot] : slot;
+                    const uint32_t gt = lt * job.tile_ranks + job.tile_rank;
+                    blk_base = base;
+                    blk_px0 = (gt % job.tiles_x) * RTC_TILE_W + blk * 8;
+                    blk_py0 = (gt / job.tiles_x) * RTC_TILE_H;
+                    blk_valid = gt < job.tiles_total;
+                    // canvas index of the block's first pixel, or its slot in the rank's dense tile buffer
+                    blk_out0 = job.tile_ranks == 1 ? ((long long)blk_py0 * job.hsize + blk_px0) * 3
+                                                   : ((long long)lt * tile_px + blk * 8) * 3;
+                }
             }
             const uint32_t avail = loc_end - loc_next;
             const uint32_t rank_in_wave = (uint32_t)__popcll(idle & lanes_below);
@@ -755,27 +777,21 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     out_index = (long long)k * 3;
                     got_work = true;
                 } else {
-                    // queue position k -> (local tile, 8x8 block of the tile, pixel of the block)
-                    const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
-                    const uint32_t slot = k / tile_px, r = k % tile_px;
-                    const uint32_t lt = g_tile_order ? g_tile_order[slot] : slot;
-                    const uint32_t tx = (r / 64) * 8 + (r % 8), ty = (r % 64) / 8;
-                    const uint32_t gt = lt * job.tile_ranks + job.tile_rank;
-                    const uint32_t px = (gt % job.tiles_x) * RTC_TILE_W + tx;
-                    const uint32_t py = (gt / job.tiles_x) * RTC_TILE_H + ty;
-                    if (gt < job.tiles_total && px < job.hsize && py < job.vsize) {
+                    // pixel of the block: 8 positions per row
+                    const uint32_t r = k - blk_base;
+                    const uint32_t tx = r % 8, ty = r / 8;
+                    const uint32_t px = blk_px0 + tx, py = blk_py0 + ty;
+                    if (blk_valid && px < job.hsize && py < job.vsize) {
                         // Camera.rayForPixel (camera.zig:48-72)
                         const double x_offset = ((double)px + 0.5) * job.pixel_size;
                         const double y_offset = ((double)py + 0.5) * job.pixel_size;
                         const double world_x = job.half_width - x_offset;
                         const double world_y = job.half_height - y_offset;
                         const V3 pixel = xform_point(job.cam_inv, V3{world_x, world_y, -1.0});
-                        const V3 origin = xform_point(job.cam_inv, V3{0.0, 0.0, 0.0});
-                        ro = origin;
-                        rd = normalize3(V3{pixel.x - origin.x, pixel.y - origin.y, pixel.z - origin.z});
-                        // canvas index, or the slot of the rank's dense tile buffer (row-major in the tile)
-                        out_index = job.tile_ranks == 1 ? ((long long)py * job.hsize + px) * 3
-                                                        : ((long long)lt * tile_px + ty * RTC_TILE_W + tx) * 3;
+                        ro = cam_origin;
+                        rd = normalize3(V3{pixel.x - cam_origin.x, pixel.y - cam_origin.y, pixel.z - cam_origin.z});
+                        const long long row_stride = job.tile_ranks == 1 ? (long long)job.hsize : (long long)RTC_TILE_W;
+                        out_index = blk_out0 + ((long long)ty * row_stride + tx) * 3;
                         got_work = true;
                     }
                 }
