@@ -182,7 +182,7 @@ struct RtcScene {
     int32_t* d_order = nullptr;
     int32_t group[5] = {0, 0, 0, 0, 0};
     rtc::DevShade* d_shade = nullptr;
-    uint32_t* d_counter = nullptr;  // work-queue head (4 B) followed by 5 x uint64 stats
+    uint32_t* d_counter = nullptr;  // control block: work-queue heads, statistics counters (see rtc_internal.h)
     uint64_t* d_stats = nullptr;
     double light_pos[3] = {0, 0, 0};
     double light_int[3] = {0, 0, 0};
@@ -535,7 +535,7 @@ int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, 
         return RTC_OK;
     }
     // zero the queue head and the stats words
-    HIP_TRY(hipMemsetAsync(s->d_counter, 0, 64, stream));
+    HIP_TRY(hipMemsetAsync(s->d_counter, 0, rtc::kProbeOffsetBytes, stream));
     if (stats) HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(rtc::launch_render(dev_world(s), job, stats != nullptr, stream));
     if (stats) {
@@ -748,8 +748,8 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     } while (0)
     SCENE_TRY(hipMalloc((void**)&sc->d_tab, tab.size() * sizeof(double)));
     SCENE_TRY(hipMalloc((void**)&sc->d_shade, n_alloc * sizeof(rtc::DevShade)));
-    SCENE_TRY(hipMalloc((void**)&sc->d_counter, 64 + 19 * 8 * 8192));  // queue head, stats, developer probe area
-    sc->d_stats = (uint64_t*)((char*)sc->d_counter + 8);
+    SCENE_TRY(hipMalloc((void**)&sc->d_counter, rtc::kProbeOffsetBytes + 19 * 8 * 8192));  // + developer probe area
+    sc->d_stats = (uint64_t*)((char*)sc->d_counter + rtc::kStatsOffsetBytes);
     SCENE_TRY(hipEventCreate(&sc->ev_start));
     SCENE_TRY(hipEventCreate(&sc->ev_stop));
     SCENE_TRY(hipMalloc((void**)&sc->d_order, order.size() * sizeof(int32_t)));
@@ -953,7 +953,7 @@ int rtc_arith_probe(const double* a, const double* b, uint64_t n, double* out_di
 #ifdef RTC_PROBE
 int rtc_debug_probe(RtcScene* scene, uint64_t* out, uint64_t n_waves) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, (char*)scene->d_counter + 64, 19 * 8 * 8192, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, (char*)scene->d_counter + rtc::kProbeOffsetBytes, 19 * 8 * 8192, hipMemcpyDeviceToHost));
     return RTC_OK;
 }
 #endif

@@ -16,6 +16,16 @@ constexpr int kMaxDepthLarge = 16;
 
 // Per-shape record read by one lane after it knows which shape it hit (a gather).
 // Everything a hit needs that the sweep table does not hold.
+// Per-scene control block in device memory: the heads of the work queues (one 128-byte line
+// each), then 64 bytes of statistics counters, then the developer probe area.
+#ifndef RTC_QUEUES
+#define RTC_QUEUES 16
+#endif
+constexpr int kQueues = RTC_QUEUES;
+constexpr int kQueueStrideWords = 32;  // uint32 words between queue heads
+constexpr int kStatsOffsetBytes = kQueues * kQueueStrideWords * 4;
+constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 64;
+
 constexpr int kRecordDoubles = 20;  // doubles per sweep-table record (see DevWorld)
 
 struct DevShade {
@@ -86,7 +96,7 @@ struct DevJob {
     const uint32_t* tile_order;
     int32_t depth;
     double* out;
-    uint32_t* counter;  // work-queue head, zeroed before the launch
+    uint32_t* counter;  // control block: the work-queue heads first, zeroed before the launch
     uint64_t* stats;    // 5 counters (radiance, shadow, sphere hits, plane hits, shaded) or nullptr
 };
 

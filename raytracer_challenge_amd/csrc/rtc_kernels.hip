@@ -593,7 +593,12 @@ struct FrameSlots {
     int meta[kLdsFrames][kBlock];
 };
 enum : int { kIdle = 0, kRun = 1, kHelperDone = 2 };
-constexpr int kChunk = 64;  // queue positions a wave draws at a time: one 8x8 block of pixels
+constexpr int kChunk = 64;  // queue positions a wave deals out at a time: one 8x8 block of pixels
+
+// Number of set bits of a wave-wide mask below the calling lane (v_mbcnt).
+__device__ __forceinline__ uint32_t set_bits_below_lane(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 
 // Lane id of the n-th (0-based) set bit of mask; n < popcount(mask).
 __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
@@ -663,7 +668,6 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             return g_tab + (size_t)i * kRecDoubles;
     };
     const int lane = (int)(threadIdx.x & 63);
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     DevWorld w = wc;
     w.tab = g_tab;
     w.shade = g_shade;
@@ -712,17 +716,20 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     int wait_lane = 0;         // ... that lane
     int owner = 0;             // helper: the lane whose frame consumes this task's colour
     int base_rem = 0;          // `remaining` (calc.zig:641) of the task's root ray
-    long long out_index = -1;  // root: where the pixel goes
+    uint32_t out_pixel = 0;    // root: the pixel's slot in the output (three doubles each)
     int sp = 0;
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
-    V3 res = {0, 0, 0};        // helper: finished colour, held until the owner has read it
     bool exhausted = false;    // wave-uniform: the global pixel queue is empty
     uint32_t loc_next = 0, loc_end = 0;  // wave-uniform: the chunk of queue positions the wave is dealing out
+    // One queue head would be an atomic on one address for the whole GPU: about 85 M of them per
+    // second go through, which a frame of cheap pixels exceeds.  The blocks are dealt round-robin
+    // to kQueues heads on separate cache lines; a wave starts at the queue its index selects.
+    uint32_t cur_queue = ((blockIdx.x * (kBlock / 64)) + (threadIdx.x >> 6)) % kQueues;
 
     // wave-uniform: the 8x8 block the current draw covers
     uint32_t blk_base = 0, blk_px0 = 0, blk_py0 = 0;
     bool blk_valid = false;
-    long long blk_out0 = 0;
+    uint32_t blk_out0 = 0;
     // inverse(camera.transform) * point(0,0,0) (camera.zig:60): the same value for every pixel,
     // evaluated once on the host with the same expression
     const V3 cam_origin = {job.cam_origin[0], job.cam_origin[1], job.cam_origin[2]};
@@ -759,18 +766,35 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             if (idle == 0) break;
             if (loc_next >= loc_end) {
                 if (exhausted) break;
-                const int leader = (int)__ffsll((long long)idle) - 1;
-                uint32_t base = 0;
-                const uint32_t chunk = (uint32_t)kChunk;
-                if (lane == leader) base = atomicAdd(g_counter, chunk);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)base, leader));
-                if (base + chunk >= job.total || base + chunk < base) exhausted = true;
+                // Draw the next block of this wave's current queue.  Queue q hands out the blocks
+                // q, q + kQueues, q + 2 kQueues, ...; a queue that has run out sends the wave on to
+                // the next open one, and once all have run out the wave is done drawing.
+                const uint32_t n_blocks = (job.total + (uint32_t)kChunk - 1) / (uint32_t)kChunk;
+                uint32_t turn = 0;
+                if (lane == 0) turn = atomicAdd(g_counter + cur_queue * kQueueStrideWords, 1u);
+                turn = (uint32_t)__builtin_amdgcn_readfirstlane((int)turn);
+                const unsigned long long block = (unsigned long long)turn * kQueues + cur_queue;
+                if (block >= n_blocks) {
+                    // one look at all heads (they only grow, so a queue seen empty stays empty)
+                    uint32_t head = 0;
+                    if (lane < kQueues) head = __atomic_load_n(g_counter + lane * kQueueStrideWords, __ATOMIC_RELAXED);
+                    const bool has_blocks = lane < kQueues && (unsigned long long)head * kQueues + (unsigned)lane < n_blocks;
+                    const unsigned long long open_queues = __ballot(has_blocks);
+                    if (open_queues == 0) {
+                        exhausted = true;
 #ifdef RTC_PROBE
-                if (exhausted && probe_tx == 0) probe_tx = wall_clock64();
+                        if (probe_tx == 0) probe_tx = wall_clock64();
 #endif
-                if (base >= job.total) break;
+                    } else {
+                        // the first open queue after the current one, cyclically
+                        const unsigned long long after = open_queues & ~((2ull << cur_queue) - 1ull);
+                        cur_queue = (uint32_t)__ffsll((long long)(after ? after : open_queues)) - 1u;
+                    }
+                    break;
+                }
+                const uint32_t base = (uint32_t)block * (uint32_t)kChunk;
                 loc_next = base;
-                loc_end = base + chunk < job.total ? base + chunk : job.total;
+                loc_end = base + (uint32_t)kChunk < job.total ? base + (uint32_t)kChunk : job.total;
                 if (!FROM_RAYS) {
                     // where the block lies, once per draw and wave-uniform: queue position ->
                     // (queue slot of the tile, 8x8 block of the tile) -> local tile -> global tile
@@ -782,13 +806,12 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     blk_px0 = (gt % job.tiles_x) * RTC_TILE_W + blk * 8;
                     blk_py0 = (gt / job.tiles_x) * RTC_TILE_H;
                     blk_valid = gt < job.tiles_total;
-                    // canvas index of the block's first pixel, or its slot in the rank's dense tile buffer
-                    blk_out0 = job.tile_ranks == 1 ? ((long long)blk_py0 * job.hsize + blk_px0) * 3
-                                                   : ((long long)lt * tile_px + blk * 8) * 3;
+                    // canvas pixel of the block's first pixel, or its slot in the rank's dense tile buffer
+                    blk_out0 = job.tile_ranks == 1 ? blk_py0 * job.hsize + blk_px0 : lt * tile_px + blk * 8;
                 }
             }
             const uint32_t avail = loc_end - loc_next;
-            const uint32_t rank_in_wave = (uint32_t)__popcll(idle & lanes_below);
+            const uint32_t rank_in_wave = set_bits_below_lane(idle);
             if (mode == kIdle && rank_in_wave < avail) {
                 const uint32_t k = loc_next + rank_in_wave;
                 bool got_work = false;
@@ -796,7 +819,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     const double* r = g_rays + (size_t)k * 6;
                     ro = {r[0], r[1], r[2]};
                     rd = {r[3], r[4], r[5]};
-                    out_index = (long long)k * 3;
+                    out_pixel = k;
                     got_work = true;
                 } else {
                     // pixel of the block: 8 positions per row
@@ -812,8 +835,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                         const V3 pixel = xform_point(job.cam_inv, V3{world_x, world_y, -1.0});
                         ro = cam_origin;
                         rd = normalize3(V3{pixel.x - cam_origin.x, pixel.y - cam_origin.y, pixel.z - cam_origin.z});
-                        const long long row_stride = job.tile_ranks == 1 ? (long long)job.hsize : (long long)RTC_TILE_W;
-                        out_index = blk_out0 + ((long long)ty * row_stride + tx) * 3;
+                        const uint32_t row_stride = job.tile_ranks == 1 ? job.hsize : (uint32_t)RTC_TILE_W;
+                        out_pixel = blk_out0 + ty * row_stride + tx;
                         got_work = true;
                     }
                 }
@@ -844,7 +867,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             // (1) owners waiting for a taken-over subtree read the helper's colour
             const int hl = waiting ? wait_lane : lane;
             const int h_done = __shfl((int)(mode == kHelperDone), hl);
-            const double hx = __shfl(res.x, hl), hy = __shfl(res.y, hl), hz = __shfl(res.z, hl);
+            // a finished helper keeps its colour in `ro`, which it no longer needs, until the owner has read it
+            const double hx = __shfl(ro.x, hl), hy = __shfl(ro.y, hl), hz = __shfl(ro.z, hl);
             const bool got = waiting && h_done != 0;
             const int ack = __shfl(got ? hl : -1, owner);
             if (mode == kHelperDone && ack == lane) mode = kIdle;
@@ -876,7 +900,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             if (offers != 0 && idles != 0) {
                 const int n_off = __popcll(offers), n_idle = __popcll(idles);
                 const int n_pairs = n_off < n_idle ? n_off : n_idle;
-                const int my_off = __popcll(offers & lanes_below), my_idle = __popcll(idles & lanes_below);
+                const int my_off = (int)set_bits_below_lane(offers), my_idle = (int)set_bits_below_lane(idles);
                 const bool give = offer_f >= 0 && my_off < n_pairs;
                 const bool take = mode == kIdle && my_idle < n_pairs;
                 int partner = lane;
@@ -1140,16 +1164,17 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             }
             if (!settled) {
                 if (is_helper) {
-                    res = ret;
+                    ro = ret;
                     mode = kHelperDone;
                 } else {
                     // canvas.set (canvas.zig:24-28)
 #ifdef RTC_COSTMAP
                     ret = {(double)cost_nodes, 0.0, 0.0};  // developer build: nodes traced per pixel instead of the colour
 #endif
-                    g_out[out_index + 0] = ret.x;
-                    g_out[out_index + 1] = ret.y;
-                    g_out[out_index + 2] = ret.z;
+                    double* __restrict__ px_out = g_out + (size_t)out_pixel * 3;
+                    px_out[0] = ret.x;
+                    px_out[1] = ret.y;
+                    px_out[2] = ret.z;
                     mode = kIdle;
                 }
             }
@@ -1159,7 +1184,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 
 #ifdef RTC_PROBE
     if (lane == 0) {
-        unsigned long long* pr = (unsigned long long*)((char*)g_counter + 64);
+        unsigned long long* pr = (unsigned long long*)((char*)g_counter + kProbeOffsetBytes);
         const unsigned wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         if (wid < 8192) {
             pr[wid * 3 + 0] = probe_t0;

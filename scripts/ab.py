@@ -20,12 +20,13 @@ elif wl == "c4": world, cam = scenes.synthetic_scene(3840, 2160)
 cd = cam.desc()
 sc = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
 out = torch.empty(cd.hsize * cd.vsize * 3, dtype=torch.float64, device="cuda")
-for _ in range(2): sc.render_device(cd, 5, out.data_ptr())
+DEPTH = int(os.environ.get('RTC_AB_DEPTH', '5'))
+for _ in range(2): sc.render_device(cd, DEPTH, out.data_ptr())
 torch.cuda.synchronize()
 ts = []
 for _ in range(int(sys.argv[2])):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); sc.render_device(cd, 5, out.data_ptr()); b.record(); torch.cuda.synchronize()
+    a.record(); sc.render_device(cd, DEPTH, out.data_ptr()); b.record(); torch.cuda.synchronize()
     ts.append(a.elapsed_time(b))
 import hashlib
 print(json.dumps({"ms": ts, "sha": hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12]}))
