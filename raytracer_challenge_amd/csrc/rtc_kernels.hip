@@ -593,6 +593,7 @@ struct FrameSlots {
     int meta[kLdsFrames][kBlock];
 };
 enum : int { kIdle = 0, kRun = 1, kHelperDone = 2 };
+enum : int { kAuxOwnerShift = 6, kAuxRemShift = 12, kAuxHelper = 1 << 18, kAuxWaiting = 1 << 19 };
 constexpr int kChunk = 64;  // queue positions a wave deals out at a time: one 8x8 block of pixels
 
 // Number of set bits of a wave-wide mask below the calling lane (v_mbcnt).
@@ -711,11 +712,13 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     // whole pixel (root) or, once the pixel queue is empty, a refracted subtree taken over
     // from a busy lane of the same wave.
     int mode = kIdle;
-    bool is_helper = false;    // the task is a taken-over subtree: its colour goes to `owner`, not to the canvas
-    bool waiting = false;      // top frame waits for a subtree another lane is tracing
-    int wait_lane = 0;         // ... that lane
-    int owner = 0;             // helper: the lane whose frame consumes this task's colour
-    int base_rem = 0;          // `remaining` (calc.zig:641) of the task's root ray
+    // The rest of the task state in one word (registers are the scarce resource of this kernel):
+    //   bits 0-5   wait lane: the lane tracing the subtree this lane's top frame waits for (kAuxWaiting)
+    //   bits 6-11  owner: for a helper, the lane whose frame consumes this task's colour
+    //   bits 12-17 `remaining` (calc.zig:641) of the task's root ray
+    //   kAuxHelper  the task is a taken-over subtree: its colour goes to the owner, not to the canvas
+    //   kAuxWaiting the top frame waits for a subtree another lane is tracing
+    int aux = 0;
     uint32_t out_pixel = 0;    // root: the pixel's slot in the output (three doubles each)
     int sp = 0;
     V3 ro = {0, 0, 0}, rd = {0, 0, 0};
@@ -845,9 +848,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     cost_nodes = 0;
 #endif
                     mode = kRun;
-                    is_helper = false;
-                    waiting = false;
-                    base_rem = job.depth;
+                    aux = job.depth << kAuxRemShift;
                     sp = 0;
                 }
             }
@@ -865,12 +866,13 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
         // traces it, and the owner combines it at the same place in its post-order unwinding.
         if (drained) {
             // (1) owners waiting for a taken-over subtree read the helper's colour
-            const int hl = waiting ? wait_lane : lane;
+            const bool waiting = (aux & kAuxWaiting) != 0;
+            const int hl = waiting ? (aux & 63) : lane;
             const int h_done = __shfl((int)(mode == kHelperDone), hl);
             // a finished helper keeps its colour in `ro`, which it no longer needs, until the owner has read it
             const double hx = __shfl(ro.x, hl), hy = __shfl(ro.y, hl), hz = __shfl(ro.z, hl);
             const bool got = waiting && h_done != 0;
-            const int ack = __shfl(got ? hl : -1, owner);
+            const int ack = __shfl(got ? hl : -1, (aux >> kAuxOwnerShift) & 63);
             if (mode == kHelperDone && ack == lane) mode = kIdle;
             if (got) {
                 // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
@@ -884,7 +886,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 const V3 a0 = frame_acc(f);
                 ret = {a0.x + c.x, a0.y + c.y, a0.z + c.z};
                 --sp;
-                waiting = false;
+                aux &= ~kAuxWaiting;
                 have_ret = true;
             }
             // (2) match parked refracted subtrees (shallowest first) with idle lanes
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     for (int q = 0; q < 6; ++q) p[q] = f_ray[offer_f][q];
                     set_frame_meta(offer_f, frame_meta(offer_f) | kOutsourced | (partner << kMetaPartnerShift));
                 }
-                const int p_rem = base_rem - offer_f - 1;
+                const int p_rem = ((aux >> kAuxRemShift) & 63) - offer_f - 1;
                 double t6[6];
 #pragma unroll
                 for (int q = 0; q < 6; ++q) t6[q] = __shfl(p[q], partner);
@@ -920,12 +922,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 if (take) {
                     ro = {t6[0], t6[1], t6[2]};
                     rd = {t6[3], t6[4], t6[5]};
-                    base_rem = t_rem;
+                    aux = (t_rem << kAuxRemShift) | kAuxHelper | (partner << kAuxOwnerShift);
                     sp = 0;
                     mode = kRun;
-                    is_helper = true;
-                    waiting = false;
-                    owner = partner;
                 }
             }
         }
@@ -939,13 +938,13 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #ifdef RTC_PROBE
         ++pcv[pc_iters];
 #endif
-        if (mode == kRun && !waiting && !have_ret) {
+        if (mode == kRun && !(aux & kAuxWaiting) && !have_ret) {
             // ---- one tree node: calc.worldColorAt (calc.zig:641-652) ---------------------
             if (STATS) ++n_radiance;
 #ifdef RTC_COSTMAP
             ++cost_nodes;
 #endif
-            const int remaining = base_rem - sp;
+            const int remaining = ((aux >> kAuxRemShift) & 63) - sp;
             Sweep hit;
             sweep_world<false, STATS, ACCEL>(g_tab, g_order, w, ro, rd, hit, containers, ctr);
             RTC_STAMP(pc_sweep1);
@@ -1138,8 +1137,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                             set_frame_acc(L, acc);
                             set_frame_meta(L, flags | kWaitRefract);
                             if (flags & kOutsourced) {
-                                waiting = true;
-                                wait_lane = (flags >> kMetaPartnerShift) & 63;
+                                aux = (aux & ~63) | kAuxWaiting | ((flags >> kMetaPartnerShift) & 63);
                             } else {
                                 ro = {f_ray[L][0], f_ray[L][1], f_ray[L][2]};
                                 rd = {f_ray[L][3], f_ray[L][4], f_ray[L][5]};
@@ -1163,7 +1161,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 }
             }
             if (!settled) {
-                if (is_helper) {
+                if (aux & kAuxHelper) {
                     ro = ret;
                     mode = kHelperDone;
                 } else {
