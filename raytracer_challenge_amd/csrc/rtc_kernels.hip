@@ -587,7 +587,10 @@ __device__ __forceinline__ V3 pattern_color(const DevShade& sh, const double* __
 // L2, and every push and pop would travel to HBM and back.
 enum : int { kHasRefract = 1, kSchlick = 2, kWaitRefract = 4, kOutsourced = 8 };
 constexpr int kMetaPartnerShift = 4, kMetaShapeShift = 10;  // meta = flags | lane << 4 | shape << 10
-constexpr int kLdsFrames = 3;
+#ifndef RTC_LDS_FRAMES
+#define RTC_LDS_FRAMES 3
+#endif
+constexpr int kLdsFrames = RTC_LDS_FRAMES;
 struct FrameSlots {
     double acc[kLdsFrames][3][kBlock];
     int meta[kLdsFrames][kBlock];
