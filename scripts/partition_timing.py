@@ -1,0 +1,29 @@
+"""Developer tool: kernel time of one rank's share of the 4K Ch. 11 frame for 1, 2, 4, 8 ranks
+(interleaved tiles), i.e. what the render leg of an N-GPU run costs per GPU."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+from raytracer_challenge_amd import native, scenes
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+hs, vs = {"c3": (3840, 2160), "c5": (7680, 4320), "c2": (1920, 1080)}[wl]
+world, cam = scenes.draw_world_scene(hs, vs)
+cd = cam.desc()
+sc = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
+full = None
+for ranks in (1, 2, 4, 8):
+    n = native.tile_buffer_doubles(cd, 0, ranks)
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    worst = 0.0
+    for r in range(ranks if ranks <= 2 else 2):
+        for _ in range(3):
+            sc.render_device(cd, 5, out.data_ptr(), r, ranks)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(10):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); sc.render_device(cd, 5, out.data_ptr(), r, ranks); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        worst = max(worst, sorted(ts)[len(ts) // 2])
+    if ranks == 1:
+        full = worst
+    print(f"{wl} ranks {ranks}: render {worst:.3f} ms per rank; render-only efficiency {full / (ranks * worst):.2f}")
