@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 from raytracer_challenge_amd import native, scenes
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
-world, cam = {"c3": lambda: scenes.draw_world_scene(3840, 2160), "c2": lambda: scenes.draw_world_scene(1920, 1080), "c5": lambda: scenes.draw_world_scene(7680, 4320),
+world, cam = {"c3": lambda: scenes.draw_world_scene(3840, 2160), "c2": lambda: scenes.draw_world_scene(1920, 1080), "tiny": lambda: scenes.draw_world_scene(128, 64), "c5": lambda: scenes.draw_world_scene(7680, 4320),
               "c4m": lambda: scenes.synthetic_scene(1920, 1080)}[wl]()
 cd = cam.desc()
 sc = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
