@@ -16,11 +16,15 @@
 // that is unwound in the reference's post-order, so the colour sums associate exactly as
 // in calc.zig:464-469.  Every loop iteration each live lane processes one tree node: a
 // radiance sweep over all shapes, then (on a hit) a shadow sweep and the shading.  The
-// sweep is brute force over the whole shape list, exactly the reference's list order, and
-// is identical work for every lane whatever ray it holds, so a wavefront never diverges
-// inside it; shape rows are read with wave-uniform addresses.  Lanes that finish a pixel
-// take the next one from a global queue (one atomic per wave, ballot + prefix count to
-// hand out indices), so lanes stay busy until the image is exhausted.
+// sweep tests every shape, as calc.intersectWorld does; the shapes are visited group by
+// group (four kinds, one specialised loop each) rather than in list order, and equal t are
+// resolved by list index, which selects what the reference's stable sort selects.  It is the
+// same work for every lane whatever ray it holds, so a wavefront does not diverge over the
+// shape list; the records are read with wave-uniform addresses into scalar registers.
+// Lanes that finish a pixel take the next one from the 8x8 block their wave is dealing out;
+// waves draw blocks from sixteen striped queues, costliest rows of tiles first; at the end of
+// the frame idle lanes take over parked subtrees of busy lanes of their wave.  What a hit
+// gathers per lane and the top of the frame stacks live in LDS.
 #include "rtc_internal.h"
 
 #pragma clang fp contract(off)
