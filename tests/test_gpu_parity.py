@@ -305,6 +305,18 @@ def test_grazing_rays_on_small_large_far_and_stretched_spheres(seed):
     assert 0.2 < hit.mean() < 0.995  # the set straddles hit and miss
 
 
+def test_worlds_beyond_the_lds_table_size_and_one_kind_worlds():
+    """More than 32 shapes: what a hit gathers comes from global memory instead of the LDS copy;
+    worlds of spheres only / planes only leave sweep groups empty."""
+    for seed in (11, 12):
+        w, c = random_world(seed, n_spheres=45, n_planes=4)
+        assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), f"49 shapes, seed {seed}")
+    w, c = random_world(13, n_spheres=9, n_planes=0)
+    assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), "spheres only")
+    w, c = random_world(14, n_spheres=0, n_planes=5)
+    assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), "planes only")
+
+
 def test_nested_glass_world():
     w, c = nested_glass_world()
     assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), "nested glass")
