@@ -488,6 +488,9 @@ def test_full_size_frame_properties():
         torch.cuda.synchronize()
         assert torch.equal(canvas, full)
         host = full.cpu().numpy().reshape(vs, hs, 3)
+        # the host-buffer entry point (staged through pinned memory at this size), twice
+        assert np.array_equal(sc.render(cd, 5), host)
+        assert np.array_equal(sc.render(cd, 5), host)
         # host-side mirror of the partition agrees with the device's
         g = gathered.cpu().numpy().reshape(ranks, -1, 3)
         assert np.array_equal(tiles.deinterleave(g, hs, vs, ranks), host)
