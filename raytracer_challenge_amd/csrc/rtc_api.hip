@@ -357,10 +357,17 @@ RtcScene::SphereBox sphere_box(const double* b, int32_t pos, double scene_extent
     return box;
 }
 
-// Balanced hierarchy by median split along the widest axis of the centres; returns the child
-// code of the subtree over items[begin, end).
+// Hierarchy over items[begin, end); returns the child code of the subtree.  Split by the surface
+// area heuristic over 16 bins of the centres along each axis; where that finds no split (all
+// centres in one bin) or the tree is already kMaxSahDepth deep, by the median along the widest
+// axis, which halves the range, so the depth stays below kMaxSahDepth + 21 < the traversal stack.
+constexpr int kMaxSahDepth = 40;
+inline double half_area(const double lo[3], const double hi[3]) {
+    const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return x * y + y * z + z * x;
+}
 int32_t build_bvh(std::vector<RtcScene::SphereBox>& items, size_t begin, size_t end, std::vector<rtc::BvhNode>& nodes,
-                  double lo[3], double hi[3]) {
+                  double lo[3], double hi[3], int depth = 0) {
     if (end - begin == 1) {
         for (int a = 0; a < 3; ++a) {
             lo[a] = items[begin].lo[a];
@@ -368,27 +375,98 @@ int32_t build_bvh(std::vector<RtcScene::SphereBox>& items, size_t begin, size_t 
         }
         return ~items[begin].pos;
     }
+    auto centre = [](const RtcScene::SphereBox& x, int a) { return 0.5 * x.lo[a] + 0.5 * x.hi[a]; };
     double cmin[3] = {1e300, 1e300, 1e300}, cmax[3] = {-1e300, -1e300, -1e300};
+    bool finite = true;
     for (size_t k = begin; k < end; ++k)
         for (int a = 0; a < 3; ++a) {
-            const double c = 0.5 * items[k].lo[a] + 0.5 * items[k].hi[a];
+            const double c = centre(items[k], a);
+            finite = finite && std::isfinite(items[k].lo[a]) && std::isfinite(items[k].hi[a]);
             if (c < cmin[a]) cmin[a] = c;
             if (c > cmax[a]) cmax[a] = c;
         }
-    int axis = 0;
-    for (int a = 1; a < 3; ++a)
-        if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
-    const size_t mid = begin + (end - begin) / 2;
-    std::nth_element(items.begin() + begin, items.begin() + mid, items.begin() + end,
-                     [axis](const RtcScene::SphereBox& x, const RtcScene::SphereBox& y) {
-                         const double cx = 0.5 * x.lo[axis] + 0.5 * x.hi[axis], cy = 0.5 * y.lo[axis] + 0.5 * y.hi[axis];
-                         return cx < cy || (cx == cy && x.pos < y.pos);
-                     });
+    size_t mid = 0;
+    bool split = false;
+    if (finite && depth < kMaxSahDepth && end - begin > 2) {
+        constexpr int kBins = 16;
+        double best = 1e300;
+        int best_axis = -1, best_bin = -1;
+        for (int a = 0; a < 3; ++a) {
+            const double width = cmax[a] - cmin[a];
+            if (!(width > 0)) continue;
+            size_t count[kBins] = {0};
+            double blo[kBins][3], bhi[kBins][3];
+            for (int b = 0; b < kBins; ++b)
+                for (int c = 0; c < 3; ++c) blo[b][c] = 1e300, bhi[b][c] = -1e300;
+            for (size_t k = begin; k < end; ++k) {
+                int b = (int)((centre(items[k], a) - cmin[a]) / width * kBins);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                ++count[b];
+                for (int c = 0; c < 3; ++c) {
+                    blo[b][c] = std::fmin(blo[b][c], items[k].lo[c]);
+                    bhi[b][c] = std::fmax(bhi[b][c], items[k].hi[c]);
+                }
+            }
+            // cost of splitting after bin b: area(left) * n(left) + area(right) * n(right)
+            double rlo[kBins][3], rhi[kBins][3];
+            size_t rcount[kBins];
+            double accl[3] = {1e300, 1e300, 1e300}, acch[3] = {-1e300, -1e300, -1e300};
+            size_t n = 0;
+            for (int b = kBins - 1; b >= 0; --b) {
+                for (int c = 0; c < 3; ++c) {
+                    accl[c] = std::fmin(accl[c], blo[b][c]);
+                    acch[c] = std::fmax(acch[c], bhi[b][c]);
+                    rlo[b][c] = accl[c];
+                    rhi[b][c] = acch[c];
+                }
+                n += count[b];
+                rcount[b] = n;
+            }
+            double ll[3] = {1e300, 1e300, 1e300}, lh[3] = {-1e300, -1e300, -1e300};
+            size_t ln = 0;
+            for (int b = 0; b + 1 < kBins; ++b) {
+                for (int c = 0; c < 3; ++c) {
+                    ll[c] = std::fmin(ll[c], blo[b][c]);
+                    lh[c] = std::fmax(lh[c], bhi[b][c]);
+                }
+                ln += count[b];
+                if (ln == 0 || rcount[b + 1] == 0) continue;
+                const double cost = half_area(ll, lh) * (double)ln + half_area(rlo[b + 1], rhi[b + 1]) * (double)rcount[b + 1];
+                if (cost < best) {
+                    best = cost;
+                    best_axis = a;
+                    best_bin = b;
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const double width = cmax[a] - cmin[a];
+            auto it = std::partition(items.begin() + begin, items.begin() + end, [&](const RtcScene::SphereBox& x) {
+                int b = (int)((centre(x, a) - cmin[a]) / width * kBins);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b <= best_bin;
+            });
+            mid = (size_t)(it - items.begin());
+            split = mid > begin && mid < end;
+        }
+    }
+    if (!split) {
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+        mid = begin + (end - begin) / 2;
+        std::nth_element(items.begin() + begin, items.begin() + mid, items.begin() + end,
+                         [&](const RtcScene::SphereBox& x, const RtcScene::SphereBox& y) {
+                             const double cx = centre(x, axis), cy = centre(y, axis);
+                             return cx < cy || (cx == cy && x.pos < y.pos);
+                         });
+    }
     const size_t index = nodes.size();
     nodes.emplace_back();
     double l[2][3], h[2][3];
-    const int32_t c0 = build_bvh(items, begin, mid, nodes, l[0], h[0]);
-    const int32_t c1 = build_bvh(items, mid, end, nodes, l[1], h[1]);
+    const int32_t c0 = build_bvh(items, begin, mid, nodes, l[0], h[0], depth + 1);
+    const int32_t c1 = build_bvh(items, mid, end, nodes, l[1], h[1], depth + 1);
     rtc::BvhNode& n = nodes[index];
     std::memset(&n, 0, sizeof n);
     n.child[0] = c0;

@@ -463,7 +463,7 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
 // both roots behind the origin, or the nearer root beyond the hit (a sphere around the origin
 // has the origin in its box and is always reached, so the containers are complete).  The
 // order of the visits does not matter: sweep_shape resolves equal t by list index.
-constexpr int kBvhStack = 32;  // the tree is balanced: depth <= ceil(log2(2^21 spheres)) = 21
+constexpr int kBvhStack = 64;  // the builder keeps the depth below 40 + ceil(log2(2^21 spheres)) = 61
 template <bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab, const int* __restrict__ order_of,
                                                   const DevWorld& w, const V3& o, const V3& d, double dd, Sweep& s,
@@ -474,48 +474,63 @@ __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab
     const bool prune = fabs(o.x) <= lim && fabs(o.y) <= lim && fabs(o.z) <= lim && dd > 0.0 && dd < inf;
     const V3 inv = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};
     int stack[kBvhStack];
+    double stack_near[kBvhStack];  // where the ray enters the deferred child's box
     int sp = 0;
     int cur = w.bvh_root;
     for (;;) {
         if (cur < 0) {
             const int pos = ~cur;
             const ShapeRec rec = load_rec(tab, pos);
-            sweep_shape<kSphereGeneral, SHADOW, STATS>(rec, pos, order_of, o, d, dd, s, cs, ctr);
+            // the table keeps the spheres with a diagonal inverse first: they need six of the twelve entries
+            if (pos < w.group[1])
+                sweep_shape<kSphereAxis, SHADOW, STATS>(rec, pos, order_of, o, d, dd, s, cs, ctr);
+            else
+                sweep_shape<kSphereGeneral, SHADOW, STATS>(rec, pos, order_of, o, d, dd, s, cs, ctr);
             if (SHADOW && s.idx >= 0) break;  // calc.isShadowed only asks whether anything is in the way
-            if (sp == 0) break;
-            cur = stack[--sp];
-            continue;
-        }
-        const BvhNode* __restrict__ n = w.bvh + cur;
-        const double reach = (SHADOW || s.idx >= 0) ? s.t * kOnePlus : inf;
-        bool enter[2];
-        double tnear[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            // fmin/fmax drop a NaN operand (0 * inf when the origin lies on a slab of an axis the
-            // ray is parallel to): that axis then constrains nothing
-            const double x1 = (n->lo[k][0] - o.x) * inv.x, x2 = (n->hi[k][0] - o.x) * inv.x;
-            const double y1 = (n->lo[k][1] - o.y) * inv.y, y2 = (n->hi[k][1] - o.y) * inv.y;
-            const double z1 = (n->lo[k][2] - o.z) * inv.z, z2 = (n->hi[k][2] - o.z) * inv.z;
-            const double t0 = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmin(z1, z2));
-            const double t1 = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
-            const bool missed = t0 > t1 || t1 < 0.0 || t0 > reach;
-            enter[k] = !(prune && missed);
-            tnear[k] = t0;
-        }
-        const int c0 = n->child[0], c1 = n->child[1];
-        if (enter[0] && enter[1]) {
-            const bool first0 = !(tnear[1] < tnear[0]);
-            stack[sp++] = first0 ? c1 : c0;
-            cur = first0 ? c0 : c1;
-        } else if (enter[0]) {
-            cur = c0;
-        } else if (enter[1]) {
-            cur = c1;
         } else {
-            if (sp == 0) break;
-            cur = stack[--sp];
+            const BvhNode* __restrict__ n = w.bvh + cur;
+            const double reach = (SHADOW || s.idx >= 0) ? s.t * kOnePlus : inf;
+            bool enter[2];
+            double tnear[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                // fmin/fmax drop a NaN operand (0 * inf when the origin lies on a slab of an axis the
+                // ray is parallel to): that axis then constrains nothing
+                const double x1 = (n->lo[k][0] - o.x) * inv.x, x2 = (n->hi[k][0] - o.x) * inv.x;
+                const double y1 = (n->lo[k][1] - o.y) * inv.y, y2 = (n->hi[k][1] - o.y) * inv.y;
+                const double z1 = (n->lo[k][2] - o.z) * inv.z, z2 = (n->hi[k][2] - o.z) * inv.z;
+                const double t0 = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmin(z1, z2));
+                const double t1 = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
+                const bool missed = t0 > t1 || t1 < 0.0 || t0 > reach;
+                enter[k] = !(prune && missed);
+                tnear[k] = t0;
+            }
+            const int c0 = n->child[0], c1 = n->child[1];
+            if (enter[0] && enter[1]) {
+                const bool first0 = !(tnear[1] < tnear[0]);
+                stack[sp] = first0 ? c1 : c0;
+                stack_near[sp] = first0 ? tnear[1] : tnear[0];
+                ++sp;
+                cur = first0 ? c0 : c1;
+                continue;
+            }
+            if (enter[0] || enter[1]) {
+                cur = enter[0] ? c0 : c1;
+                continue;
+            }
         }
+        // next deferred child whose box the ray still reaches before the best hit found meanwhile
+        const double reach = (SHADOW || s.idx >= 0) ? s.t * kOnePlus : inf;
+        bool found = false;
+        while (sp > 0) {
+            --sp;
+            if (!(prune && stack_near[sp] > reach)) {
+                cur = stack[sp];
+                found = true;
+                break;
+            }
+        }
+        if (!found) break;
     }
 }
 
