@@ -1,0 +1,24 @@
+"""Developer tool: wall time of the first rtc_render_device call on a new scene (queue plan, uploads)
+against later calls with the same camera, 4K Ch. 11 frame."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+from raytracer_challenge_amd import native, scenes
+world, cam = scenes.draw_world_scene(3840, 2160)
+cd = cam.desc()
+out = torch.empty(cd.hsize * cd.vsize * 3, dtype=torch.float64, device="cuda")
+warm = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
+warm.render_device(cd, 5, out.data_ptr()); torch.cuda.synchronize()
+first, later = [], []
+for _ in range(5):
+    t0 = time.perf_counter()
+    sc = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
+    t1 = time.perf_counter()
+    sc.render_device(cd, 5, out.data_ptr()); torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    sc.render_device(cd, 5, out.data_ptr()); torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    first.append((t1 - t0, t2 - t1)); later.append(t3 - t2)
+    sc.close()
+print("scene create %.3f ms; first frame %.3f ms; later frames %.3f ms" % (
+    1e3 * min(a for a, _ in first), 1e3 * min(b for _, b in first), 1e3 * min(later)))
