@@ -521,6 +521,8 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
     const uint32_t tiles_x = job->tiles_x, ranks = job->tile_ranks, rank = job->tile_rank;
     const uint32_t tiles_y = job->tiles_total / tiles_x;
     std::vector<uint64_t> row_score(tiles_y, 0);
+    struct TileBox { uint32_t tx0, tx1, ty0, ty1; };
+    std::vector<TileBox> boxes;
     const double* T = cam->transform;  // world -> camera; the camera looks down -z (camera.zig:48-72)
     const double stretch = largest_stretch(T);
     bool any = false;
@@ -547,6 +549,7 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
         const uint32_t tx1 = px1 < (double)cam->hsize ? (uint32_t)(px1 / RTC_TILE_W) : tiles_x - 1;
         const uint32_t ty1 = py1 < (double)cam->vsize ? (uint32_t)(py1 / RTC_TILE_H) : tiles_y - 1;
         for (uint32_t ty = ty0; ty <= ty1 && ty < tiles_y; ++ty) row_score[ty] += (uint64_t)(tx1 - tx0 + 1);
+        boxes.push_back({tx0, tx1, ty0, ty1});
         any = true;
     }
     s->plan_camera = *cam;
@@ -584,6 +587,24 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
     for (uint32_t i = 0; i < tiles_y; ++i) start[i + 1] += start[i];
     std::vector<uint32_t> order(local_tiles);
     for (uint64_t k = 0; k < local_tiles; ++k) order[start[rank_of_row[(k * ranks + rank) / tiles_x]]++] = (uint32_t)k;
+    // A block of 64 such pixels keeps its wave for some 60 node iterations, about 0.4 ms: on a
+    // share of the frame that the whole GPU finishes in little more than that, every one of them
+    // must be some wave's first block, so the tiles a transparent shape can show go to the front
+    // of the queue (in the row order above).  On larger shares the rows stay whole (measured at
+    // 7680x4320: 10.08 against 10.31 ms).
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const uint64_t resident_waves = (uint64_t)cus * 16;
+    if (local_tiles * (RTC_TILE_W * RTC_TILE_H / 64) <= 10 * resident_waves) {
+        auto marked = [&](uint32_t k) {
+            const uint32_t tx = (uint32_t)(((uint64_t)k * ranks + rank) % tiles_x), ty = (uint32_t)(((uint64_t)k * ranks + rank) / tiles_x);
+            for (const TileBox& b : boxes)
+                if (tx >= b.tx0 && tx <= b.tx1 && ty >= b.ty0 && ty <= b.ty1) return true;
+            return false;
+        };
+        std::stable_partition(order.begin(), order.end(), marked);
+    }
     // an earlier launch on this stream may still be reading the previous plan
     HIP_TRY(hipStreamSynchronize(stream));
     if (s->tile_order_capacity < local_tiles) {

@@ -7,9 +7,10 @@ world, cam = {"c3": lambda: scenes.draw_world_scene(3840, 2160), "c2": lambda: s
               "c4m": lambda: scenes.synthetic_scene(1920, 1080)}[wl]()
 cd = cam.desc()
 sc = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
-out = torch.empty(cd.hsize * cd.vsize * 3, dtype=torch.float64, device="cuda")
+ranks = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # probe rank 0's share of an interleaved partition
+out = torch.empty(native.tile_buffer_doubles(cd, 0, ranks), dtype=torch.float64, device="cuda")
 for _ in range(2):
-    sc.render_device(cd, 5, out.data_ptr())
+    sc.render_device(cd, 5, out.data_ptr(), 0, ranks)
 torch.cuda.synchronize()
 L = native.lib()
 n = 4096
@@ -26,6 +27,10 @@ print("exhausted at ms: min %.3f med %.3f max %.3f" % tuple(np.percentile((tx[ok
 print("end at ms: min %.3f p10 %.3f med %.3f p90 %.3f p99 %.3f max %.3f" % tuple(np.percentile((te[ok] - base) * f, [0, 10, 50, 90, 99, 100])))
 tail = (te[ok] - tx[ok]) * f
 print("per-wave (end - exhausted) ms: med %.3f p90 %.3f max %.3f" % tuple(np.percentile(tail, [50, 90, 100])))
+end = np.sort((te[ok] - base) * f)
+print("waves still running at ms:", " ".join("%.2f:%d" % (t, (end > t).sum()) for t in np.arange(0.1, end[-1], 0.05)))
+it = raw[3 * 8192:].reshape(8192, 16)[:n][ok][:, 15].astype(np.int64)
+print("iterations per wave: min %d med %d p90 %d max %d" % tuple(np.percentile(it, [0, 50, 90, 100])))
 
 pc = raw[3 * 8192:].reshape(8192, 16)[:n][ok].astype(np.float64)
 names = ["refill+steal", "sweep1", "prep", "sweep2", "gather", "pattern", "light", "children", "push", "unwind"]
