@@ -206,6 +206,14 @@ int rtc_color_at(RtcScene* scene, const double* rays, uint64_t n_rays, int32_t d
  * for n_values doubles.  Device pointers. */
 int rtc_quantize_u8_device(const void* d_rgb, uint64_t n_values, void* d_out_u8, void* hip_stream);
 
+/* Camera.render followed by byteColorValue (ppm.zig:6-9) of every channel, the first half of
+ * canvasToPPM (ppm.zig:11-38): out_rgb8 (host memory, hsize*vsize*3 bytes, same pixel and
+ * channel order as rtc_render) receives the 8-bit values the reference's writer prints, so the
+ * caller only formats text.  The colours are quantised on the device and 3 instead of 24 bytes
+ * per pixel cross to the host.  stats may be NULL. */
+int rtc_render_u8(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, uint8_t* out_rgb8,
+                  RtcStats* stats);
+
 /* rtc_deinterleave_device for quantised tile buffers: each rank quantises its dense tile buffer
  * with rtc_quantize_u8_device (one byte per value, same order), the gather moves 3 B instead of
  * 24 B per pixel, and this call scatters the gathered bytes (rank r's buffer at d_gathered_u8 +

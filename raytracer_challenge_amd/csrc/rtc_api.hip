@@ -630,8 +630,9 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
 // touch of every page) against 57 GB/s into pinned memory.  Large canvases therefore go through a
 // pinned staging buffer kept with the scene: the device copies it there slice by slice, and a few
 // host threads move finished slices on into the caller's buffer while later slices are in flight.
-int copy_canvas_to_host(RtcScene* s, const double* d_src, double* dst, size_t bytes) {
-    constexpr size_t kSlice = 16u << 20;
+int copy_canvas_to_host(RtcScene* s, const void* d_src, void* dst, size_t bytes) {
+    // 16 MiB slices for the large canvases; an 8-bit 4K canvas (25 MB) still gets six
+    const size_t kSlice = bytes >= (64u << 20) ? (16u << 20) : (4u << 20);
     if (bytes < 4 * kSlice) {
         HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
         return RTC_OK;
@@ -1022,6 +1023,28 @@ int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, doub
     int rc = rtc_render_device(scene, camera, depth, 0, 1, d_out, nullptr, stats);
     if (rc == RTC_OK) rc = copy_canvas_to_host(scene, d_out, out_rgb, bytes);
     return rc;
+}
+
+int rtc_render_u8(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, uint8_t* out_rgb8, RtcStats* stats) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!out_rgb8) return fail(RTC_ERR_INVALID_ARGUMENT, "out_rgb8 is NULL");
+    if (int rc = check_camera(camera)) return rc;
+    const size_t values = (size_t)camera->hsize * camera->vsize * 3;
+    // the f64 canvas and, behind it, its 8-bit image: both stay with the scene
+    const size_t bytes = values * sizeof(double) + values;
+    if (scene->canvas_bytes < bytes) {
+        if (scene->d_canvas) (void)hipFree(scene->d_canvas);
+        scene->d_canvas = nullptr;
+        scene->canvas_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&scene->d_canvas, bytes));
+        scene->canvas_bytes = bytes;
+    }
+    double* d_rgb = scene->d_canvas;
+    uint8_t* d_u8 = reinterpret_cast<uint8_t*>(d_rgb + values);
+    int rc = rtc_render_device(scene, camera, depth, 0, 1, d_rgb, nullptr, stats);
+    if (rc != RTC_OK) return rc;
+    HIP_TRY(rtc::launch_quantize(d_rgb, values, d_u8, nullptr));
+    return copy_canvas_to_host(scene, d_u8, out_rgb8, values);
 }
 
 int rtc_color_at(RtcScene* scene, const double* rays, uint64_t n_rays, int32_t depth, double* out_rgb,

@@ -22,9 +22,10 @@ int main(int argc, char** argv) {
         if (!in) throw SceneTextError(std::string("cannot open ") + argv[1]);
         const Scene scene = parseScene(in, hsize, vsize);
         RtcStats stats{};
-        const Canvas canvas = scene.camera.render(scene.world, depth, &stats);
+        // the colours come back as the bytes canvasToPPM (ppm.zig:11-38) would print
+        const ByteCanvas canvas = scene.camera.renderBytes(scene.world, depth, &stats);
         std::ofstream file(argv[2]);
-        canvasToPPM(canvas, file);
+        bytesToPPM(canvas, file);
         std::cerr << scene.world.objects.size() << " shapes, " << canvas.width << "x" << canvas.height << ": "
                   << stats.kernel_ms << " ms on the GPU, " << stats.radiance_rays << " radiance rays -> " << argv[2] << "\n";
     } catch (const SceneTextError& e) {

@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <optional>
 #include <ostream>
 #include <stdexcept>
@@ -170,6 +171,35 @@ inline void canvasToPPM(const Canvas& canvas, std::ostream& writer) {  // ppm.zi
     }
 }
 
+// The canvas after byteColorValue (ppm.zig:6-9): what canvasToPPM prints, three bytes per pixel.
+struct ByteCanvas {
+    size_t width = 0, height = 0;
+    std::vector<uint8_t> rgb;
+    ByteCanvas(size_t w, size_t h) : width(w), height(h), rgb(w * h * 3, 0) {}
+};
+
+// The text half of canvasToPPM (ppm.zig:11-38) for colours that were quantised on the device.
+inline void bytesToPPM(const ByteCanvas& canvas, std::ostream& writer) {
+    std::string text = "P3\n" + std::to_string(canvas.width) + " " + std::to_string(canvas.height) + "\n255\n";
+    text.reserve(text.size() + canvas.rgb.size() * 4);
+    char num[256][4];
+    int len[256];
+    for (int v = 0; v < 256; ++v) len[v] = std::snprintf(num[v], sizeof num[v], "%d", v);
+    const uint8_t* p = canvas.rgb.data();
+    for (size_t y = 0; y < canvas.height; ++y) {
+        for (size_t x = 0; x < canvas.width; ++x, p += 3) {
+            if (x > 0) text.push_back(x % 5 == 0 ? '\n' : ' ');
+            text.append(num[p[0]], (size_t)len[p[0]]);
+            text.push_back(' ');
+            text.append(num[p[1]], (size_t)len[p[1]]);
+            text.push_back(' ');
+            text.append(num[p[2]], (size_t)len[p[2]]);
+        }
+        text.push_back('\n');
+    }
+    writer.write(text.data(), (std::streamsize)text.size());
+}
+
 struct RenderError : std::runtime_error {
     int code;
     RenderError(int c, const std::string& msg) : std::runtime_error(msg), code(c) {}
@@ -230,6 +260,25 @@ struct Camera {
     // Camera.render (camera.zig:74-89) through the HIP library; the reference's depth is 5.
     Canvas render(const World& world, int depth = 5, RtcStats* stats = nullptr) const {
         Canvas canvas(hsize, vsize);
+        through_library(world, [&](RtcScene* scene, const RtcCameraDesc& cam) {
+            return rtc_render(scene, &cam, depth, &canvas.pixels[0].red, stats);
+        });
+        return canvas;
+    }
+
+    // Camera.render and the byteColorValue half of canvasToPPM (ppm.zig:6-9) in one call: the
+    // colours are quantised on the device and bytesToPPM only formats.
+    ByteCanvas renderBytes(const World& world, int depth = 5, RtcStats* stats = nullptr) const {
+        ByteCanvas canvas(hsize, vsize);
+        through_library(world, [&](RtcScene* scene, const RtcCameraDesc& cam) {
+            return rtc_render_u8(scene, &cam, depth, canvas.rgb.data(), stats);
+        });
+        return canvas;
+    }
+
+    // scene upload, the call, scene release; a failure becomes a RenderError
+    template <class Call>
+    void through_library(const World& world, Call&& call) const {
         std::vector<RtcShapeDesc> shapes;
         shapes.reserve(world.objects.size());
         for (const Shape& s : world.objects) shapes.push_back(detail::flattenShape(s));
@@ -252,11 +301,10 @@ struct Camera {
         RtcScene* scene = nullptr;
         int rc = rtc_scene_create(shapes.data(), shapes.size(), &light, &scene);
         if (rc != RTC_OK) throw RenderError(rc, rtc_last_error());
-        rc = rtc_render(scene, &cam, depth, &canvas.pixels[0].red, stats);
+        rc = call(scene, cam);
         const std::string msg = rc != RTC_OK ? rtc_last_error() : "";
         rtc_scene_destroy(scene);
         if (rc != RTC_OK) throw RenderError(rc, msg);
-        return canvas;
     }
 };
 

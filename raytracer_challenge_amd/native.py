@@ -48,6 +48,7 @@ def lib():
     L.rtc_scene_set_acceleration.argtypes = [vp, i32]
     L.rtc_scene_group_counts.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
     L.rtc_render.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, dp, C.POINTER(D.RtcStats)]
+    L.rtc_render_u8.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, C.POINTER(C.c_uint8), C.POINTER(D.RtcStats)]
     L.rtc_render_device.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
     L.rtc_tile_buffer_doubles.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, C.POINTER(u64)]
     L.rtc_deinterleave_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
@@ -73,6 +74,7 @@ EXPORTS = (
     "rtc_scene_set_acceleration",
     "rtc_scene_group_counts",
     "rtc_render",
+    "rtc_render_u8",
     "rtc_render_device",
     "rtc_tile_buffer_doubles",
     "rtc_deinterleave_device",
@@ -178,6 +180,17 @@ class Scene:
         out = np.empty((camera_desc.vsize, camera_desc.hsize, 3), dtype=np.float64)
         sp = C.byref(stats) if stats is not None else None
         check(lib().rtc_render(self._h, C.byref(camera_desc), int(depth), _dptr(out), sp))
+        return out
+
+    def render_u8(self, camera_desc, depth=5, stats=None):
+        """rtc_render_u8: the canvas after byteColorValue (ppm.zig:6-9) as a (vsize, hsize, 3) uint8 array."""
+        out = np.empty((camera_desc.vsize, camera_desc.hsize, 3), dtype=np.uint8)
+        sp = C.byref(stats) if stats is not None else None
+        check(
+            lib().rtc_render_u8(
+                self._h, C.byref(camera_desc), int(depth), out.ctypes.data_as(C.POINTER(C.c_uint8)), sp
+            )
+        )
         return out
 
     def render_device(self, camera_desc, depth, d_out, tile_rank=0, tile_ranks=1, stream=None, stats=None):

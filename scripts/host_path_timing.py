@@ -21,4 +21,9 @@ ts = []
 for _ in range(5):
     t = time.perf_counter(); sc.render(cd, 5); ts.append((time.perf_counter() - t) * 1e3)
 t = time.perf_counter(); sc2 = native.Scene(world.shape_descs(), len(world.objects), world.light_desc()); create_ms = (time.perf_counter() - t) * 1e3
+sc.render_u8(cd, 5)
+t8 = []
+for _ in range(5):
+    t = time.perf_counter(); sc.render_u8(cd, 5); t8.append((time.perf_counter() - t) * 1e3)
+print(f"rtc_render_u8 (kernel + quantisation + 25 MB to the caller) min {min(t8):.1f} median {sorted(t8)[2]:.1f} ms")
 print(f"rtc_render_device {dev_ms:.2f} ms/frame; rtc_render (kernel + 199 MB to the caller's fresh pageable buffer) min {min(ts):.1f} median {sorted(ts)[2]:.1f} ms; rtc_scene_create {create_ms:.2f} ms")

@@ -506,11 +506,30 @@ def test_full_size_frame_properties():
         native.deinterleave_u8_device(cd, ranks, n0, gq.data_ptr(), q2.data_ptr())
         torch.cuda.synchronize()
         assert torch.equal(q2, q)
+        # the host entry point that returns those bytes (sliced copy at this size), twice
+        assert np.array_equal(sc.render_u8(cd, 5), byte_color_values(host))
+        assert np.array_equal(sc.render_u8(cd, 5), byte_color_values(host))
+        assert np.array_equal(sc.render(cd, 5), host)
     rows = (7, vs, 48)
     cpu = O.render(w, c, 5, O.STREAMING, rows=rows)
     sel = slice(rows[0], rows[1], rows[2])
     assert_identical(host[sel], cpu[sel], "4K sampled rows")
     assert st.pixels == hs * vs and st.radiance_rays > st.pixels
+
+
+def test_render_u8_gives_the_bytes_the_ppm_writer_prints():
+    """rtc_render_u8 = Camera.render + byteColorValue (ppm.zig:6-9) against the oracle's canvas
+    quantised on the host, on a small and a ragged canvas, with stats, alternating with rtc_render
+    on the same scene (the two share the scene's device canvas)."""
+    for size in ((90, 45), (131, 77)):
+        w, c = scenes.draw_world_scene(*size)
+        cpu = O.render(w, c, 5, O.STREAMING)
+        with scene_of(w) as sc:
+            st = D.RtcStats()
+            assert np.array_equal(sc.render_u8(c.desc(), 5, st), O.quantize_u8(cpu).reshape(cpu.shape))
+            assert st.pixels == size[0] * size[1]
+            assert_identical(sc.render(c.desc(), 5), cpu, "f64 after u8")
+            assert np.array_equal(sc.render_u8(c.desc(), 5), byte_color_values(cpu))
 
 
 def test_device_quantisation_edge_values():
