@@ -1,0 +1,63 @@
+"""Developer tool: randomised parity campaign.  Seeded random worlds (0-40 spheres, 0-4 planes,
+glass and mirrors, patterns), random canvas sizes, depths 0-7, list walk and hierarchy, whole
+canvas and interleaved partitions, each compared value for value with the CPU oracle
+(streaming integrator; every 10th world also with the literal one).  Runs until the time budget
+is spent and prints the seeds that differ.
+usage: fuzz_parity.py [seconds [first_seed]]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import numpy as np, torch
+import oracle_lib as O
+from raytracer_challenge_amd import Camera, descs as D, native
+from worlds import random_world
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+t_end = time.time() + budget
+done = bad = rays = 0
+t_print = time.time()
+while time.time() < t_end:
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    n_s, n_p = int(rng.integers(0, 41)), int(rng.integers(0, 5))
+    w, c = random_world(seed, n_spheres=n_s, n_planes=n_p, glass=bool(rng.integers(0, 4)))
+    cam = Camera(int(rng.integers(1, 97)), int(rng.integers(1, 97)), c.field_of_view)
+    cam.transform = c.transform
+    depth = int(rng.integers(0, 8))
+    cd = cam.desc()
+    cpu = O.render(w, cam, depth, O.STREAMING)
+    what = f"seed {seed}: {n_s} spheres {n_p} planes {cam.hsize}x{cam.vsize} depth {depth}"
+    try:
+        if done % 10 == 0 and cam.hsize * cam.vsize * (n_s + n_p + 1) < 60000:
+            lit = O.render(w, cam, depth, O.LITERAL)
+            assert np.array_equal(lit, cpu, equal_nan=True), "literal and streaming oracle differ"
+        sc = native.Scene(w.shape_descs(), len(w.objects), w.light_desc())
+        with sc:
+            st = D.RtcStats()
+            gpu = sc.render(cd, depth, st)
+            rays += st.radiance_rays
+            assert np.array_equal(gpu, cpu, equal_nan=True), "list walk"
+            if n_s > 0:
+                sc.set_acceleration(D.RTC_ACCEL_BVH)
+                assert np.array_equal(sc.render(cd, depth), cpu, equal_nan=True), "hierarchy"
+                assert np.array_equal(sc.render_u8(cd, depth), O.quantize_u8(cpu).reshape(cpu.shape)), "u8 (hierarchy)"
+                sc.set_acceleration(D.RTC_ACCEL_NONE)
+            ranks = int(rng.integers(2, 5))
+            n0 = native.tile_buffer_doubles(cd, 0, ranks)
+            g = torch.zeros((ranks, n0), dtype=torch.float64, device="cuda")
+            for r in range(ranks):
+                sc.render_device(cd, depth, g[r].data_ptr(), r, ranks)
+            out = torch.empty(cam.hsize * cam.vsize * 3, dtype=torch.float64, device="cuda")
+            native.deinterleave_device(cd, ranks, n0, g.data_ptr(), out.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy().reshape(cpu.shape), cpu, equal_nan=True), f"{ranks}-way partition"
+    except AssertionError as e:
+        bad += 1
+        print("DIFFERENT", what, "-", e, flush=True)
+    done += 1
+    seed += 1
+    if time.time() - t_print > 20:
+        t_print = time.time()
+        print(f"{done} worlds, {rays} radiance rays, {bad} different", flush=True)
+print(f"finished: {done} worlds, {rays} radiance rays, {bad} different (first seed {seed - done})")
+sys.exit(1 if bad else 0)
