@@ -280,7 +280,15 @@ constexpr double kOnePlus = 1.0 + 0x1p-40;
 // bounding-sphere test dismissed.
 struct SweepCounters {
     uint32_t sphere_hits, plane_hits, sphere_skips;
+#ifdef RTC_PROBE
+    uint32_t wave_full, lane_full;
+#endif
 };
+#ifdef RTC_PROBE
+// per wave of the block: sweeps, full sphere tests the wave executed, sum over sweeps of the
+// largest number of full tests a single lane needed, sum of active lanes
+__shared__ unsigned int g_probe_sweeps[4][4];
+#endif
 
 struct ShapeRec {
     double m[12];
@@ -346,6 +354,10 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
         const double oc2 = fma(oc.z, oc.z, fma(oc.y, oc.y, oc.x * oc.x));
         const double apart = fma(oc2, kBoundShrink, -rec.br2) * dd;
         if (STATS && apart > ocd * ocd) ++ctr.sphere_skips;
+#ifdef RTC_PROBE
+        if (__ballot(!(apart > ocd * ocd)) != 0) ++ctr.wave_full;
+        if (!(apart > ocd * ocd)) ++ctr.lane_full;
+#endif
         if (!(apart > ocd * ocd)) {
         // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
         V3 lo, ld;
@@ -400,11 +412,17 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
         }
         const bool hits = !(fabs(ldy) < kF64Eps);
         if (STATS && hits) ++ctr.plane_hits;
-        // sign of t = -loy/ldy from the sign of the product (a zero or underflowed product
-        // goes to the exact path); beyond the best hit when |loy| > best*|ldy|*(1+2^-40)
-        const double p = -loy * ldy;
-        const double lim = (s.t * kOnePlus) * (ldy * ldy);
-        const bool need = hits && (p < 0 ? !SHADOW : !(have && p > lim));
+        // A radiance sweep needs t of nearly every plane anyway (a plane behind the origin is a
+        // container, and some lane of the wave usually has it behind), so only the shadow sweep
+        // pays for deciding whether the division can be left out.
+        bool need = hits;
+        if (SHADOW) {
+            // sign of t = -loy/ldy from the sign of the product (a zero or underflowed product
+            // goes to the exact path); beyond the light when |loy| > dist*|ldy|*(1+2^-40)
+            const double p = -loy * ldy;
+            const double lim = (s.t * kOnePlus) * (ldy * ldy);
+            need = hits && !(p < 0) && !(p > lim);
+        }
         if (need) {
             const double t = -loy / ldy;
             cand = t;
@@ -543,6 +561,9 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     const int tid = (int)threadIdx.x;
     const double dd = fma(d.z, d.z, fma(d.y, d.y, d.x * d.x));  // for the bounding-sphere tests
     s.idx = -1;
+#ifdef RTC_PROBE
+    const uint32_t lane_full0 = ctr.lane_full, wave_full0 = ctr.wave_full;
+#endif
     if (!SHADOW) {
         s.t = 0.0;
         cs.i[0][tid] = -1;
@@ -556,6 +577,25 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
         sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, s, cs, ctr);
         sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, s, cs, ctr);
     }
+#ifdef RTC_PROBE
+    {
+        uint32_t mx = ctr.lane_full - lane_full0;
+        unsigned long long ex = __ballot(1);
+        uint32_t best = 0;
+        for (int l = 0; l < 64; ++l)
+            if ((ex >> l) & 1) {
+                const uint32_t v = (uint32_t)__shfl((int)mx, l);
+                best = v > best ? v : best;
+            }
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+            unsigned int* acc = g_probe_sweeps[threadIdx.x >> 6];
+            acc[0] += 1;
+            acc[1] += ctr.wave_full - wave_full0;
+            acc[2] += best;
+            acc[3] += (unsigned)__popcll(ex);
+        }
+    }
+#endif
     if (!SHADOW) {
         s.top1 = cs.i[0][tid];
         s.top2 = cs.i[1][tid];
@@ -725,7 +765,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     };
 
     uint32_t n_radiance = 0, n_shadow = 0, n_shaded = 0;
-    SweepCounters ctr = {0, 0, 0};
+    SweepCounters ctr = {};
 #ifdef RTC_COSTMAP
     int cost_nodes = 0;
 #endif
@@ -765,6 +805,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     const unsigned long long probe_t0 = wall_clock64();
     unsigned long long probe_tx = 0;
     unsigned long long pcv[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane < 4) g_probe_sweeps[threadIdx.x >> 6][lane] = 0;
     unsigned long long pc_mark = clock64();
     enum { pc_refill, pc_sweep1, pc_prep, pc_sweep2, pc_gather, pc_pattern, pc_light, pc_children, pc_push, pc_unwind, pc_iters = 15 };
 #define RTC_STAMP(acc)                          \
@@ -1212,6 +1253,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             pr[wid * 3 + 2] = wall_clock64();
             unsigned long long* pc = pr + 3 * 8192 + wid * 16;
             for (int q = 0; q < 16; ++q) pc[q] = pcv[q];
+            for (int q = 0; q < 4; ++q) pc[10 + q] = g_probe_sweeps[threadIdx.x >> 6][q];
         }
     }
 #endif
