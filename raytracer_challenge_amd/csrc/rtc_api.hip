@@ -815,7 +815,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         d.refractive_index = m.refractive_index;
         d.geo = s.geo;
         d.pattern = -1;
-        d.shininess_n = (m.shininess >= 1.0 && m.shininess <= 1024.0 && m.shininess == std::floor(m.shininess))
+        d.shininess_n = (m.shininess >= 1.0 && m.shininess < 500.0 && m.shininess == std::floor(m.shininess))
                             ? (int32_t)m.shininess
                             : 0;
         if (m.has_pattern) {

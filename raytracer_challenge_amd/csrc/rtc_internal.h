@@ -36,7 +36,7 @@ struct DevShade {
     double pat_inv[12];  // rows 0..2 of inverse(pattern.transform), row-major 3x4
     int32_t geo;         // RTC_GEO_*
     int32_t pattern;     // RTC_PATTERN_* or -1 when the material has no pattern
-    int32_t shininess_n; // shininess when it is an integer in [1, 1024], else 0 (see pow_small_integer)
+    int32_t shininess_n; // shininess when it is an integer in [1, 500), else 0 (see pow_small_integer)
     int32_t pad;
 };
 

@@ -212,27 +212,28 @@ __device__ double zig_pow(double x, double y) {
     return ldexp(a1, ae);
 }
 
-// zig_pow(x, n) for an integer 1 <= n <= 1024 known in advance (the shininess of a material,
-// the 2 and 5 of Schlick), by the plain multiplications its loop amounts to; x of either sign,
-// zero (frexp gives exponent 0: the products are the signed zeros zig_pow returns) or not finite
-// (the products are the infinities / NaN zig_pow returns).  That loop keeps mantissa
-// and exponent apart only against overflow and underflow: its mantissa products are the
-// products of the plain values scaled by powers of two, so the same multiplications in the
-// same order round the same way as long as every power formed (the unused last squaring
-// included, at most x^(2n)) stays in the normal range, which (|exponent of x| + 1) * 2n < 1000
-// guarantees.  Outside that range the general routine runs.
-__device__ __forceinline__ double pow_small_integer(double x, int n, double y) {
+// zig_pow(x, n) for an integer 1 <= n < 500 known in advance (the shininess of a material, the
+// 2 and 5 of Schlick), by the multiplications its loop amounts to; x of either sign, zero or
+// not finite (frexp then returns x itself with exponent 0, and the products are the signed
+// zeros, infinities or NaN zig_pow returns).  That loop squares and multiplies the mantissa of x,
+// doubles a squared mantissa that has dropped below 0.5, and adds up the exponents on the side;
+// doubling is exact, so its products are the plain products of the mantissa m of x scaled by
+// powers of two, and round the same way as long as the plain ones stay in the normal range:
+// every power formed here is at least 0.5^512.  The result is the same real number
+// m^n * 2^(e n) before the one rounding of the final ldexp.
+__device__ __forceinline__ double pow_small_integer(double x, int n) {
     int e;
-    (void)frexp(x, &e);
-    if (!((abs(e) + 1) * 2 * n < 1000)) return zig_pow(x, y);
-    double a = 1.0, p = x;
-    while (n != 0) {
-        a = (n & 1) ? a * p : a;
+    const double m = frexp(x, &e);
+    double a = 1.0, p = m;
+    int bits = n;
+    while (bits != 0) {
+        a = (bits & 1) ? a * p : a;
         p *= p;
-        n >>= 1;
+        bits >>= 1;
     }
-    return a;
+    return ldexp(a, e * n);
 }
+constexpr int kPowSmallLimit = 500;
 
 // ---------------------------------------------------------------------------------------
 // One sweep of a world ray over every shape: calc.intersectWorld (calc.zig:200-214) +
@@ -1088,9 +1089,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     const V3 lr = {nl.x - two_ln * normalv.x, nl.y - two_ln * normalv.y, nl.z - two_ln * normalv.z};
                     const double reflect_dot_eye = dot3(lr, eyev);
                     if (reflect_dot_eye > 0.0) {
-                        // reflect_dot_eye > 0 and finite here
-                        const double pw = m_shininess_n > 0 && reflect_dot_eye < __builtin_huge_val()
-                                              ? pow_small_integer(reflect_dot_eye, m_shininess_n, m_shininess)
+                        const double pw = m_shininess_n > 0
+                                              ? pow_small_integer(reflect_dot_eye, m_shininess_n)
                                               : zig_pow(reflect_dot_eye, m_shininess);
                         const double ks = m_specular * pw;
                         surface = {surface.x + ks * lint.x, surface.y + ks * lint.y, surface.z + ks * lint.z};
@@ -1132,8 +1132,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     if (tir) {
                         R = 1.0;
                     } else {
-                        const double r0 = pow_small_integer((n1 - n2) / (n1 + n2), 2, 2.0);
-                        R = r0 + (1 - r0) * pow_small_integer(1 - cosv, 5, 5.0);
+                        const double r0 = pow_small_integer((n1 - n2) / (n1 + n2), 2);
+                        R = r0 + (1 - r0) * pow_small_integer(1 - cosv, 5);
                     }
                 }
                 RTC_STAMP(pc_children);
@@ -1308,11 +1308,11 @@ __global__ __launch_bounds__(kBlock) void arith_probe_kernel(const double* __res
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         out_div[i] = a[i] / b[i];
         out_sqrt[i] = sqrt(a[i]);
-        // as the render kernel's calls are dispatched: an integer exponent in [1, 1024] takes the
+        // as the render kernel's calls are dispatched: an integer exponent in [1, 500) takes the
         // plain-multiplication path
         const double x = a[i], y = b[i];
-        const bool small_integer = y >= 1.0 && y <= 1024.0 && y == floor(y);
-        out_pow[i] = small_integer ? pow_small_integer(x, (int)y, y) : zig_pow(x, y);
+        const bool small_integer = y >= 1.0 && y < (double)kPowSmallLimit && y == floor(y);
+        out_pow[i] = small_integer ? pow_small_integer(x, (int)y) : zig_pow(x, y);
     }
 }
 

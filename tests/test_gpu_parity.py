@@ -77,6 +77,18 @@ def test_device_division_sqrt_pow_are_bit_exact():
     _, _, p = native.arith_probe(x, y)
     ref = np.array([O.zig_pow(u, v) for u, v in zip(x, y)])
     assert_identical(p.view(np.uint64), ref.view(np.uint64), "pow (integer exponents, wide range)")
+    # results in and around the subnormal range and at the overflow threshold (the one rounding
+    # of the final ldexp), subnormal and extreme bases, exponents either side of the limit of the
+    # plain-multiplication path
+    y = rng.choice([2.0, 5.0, 50.0, 200.0, 300.0, 499.0, 500.0], 30000)
+    u = np.concatenate([rng.uniform(990, 1100, 20000), rng.uniform(-1030, -1015, 10000)])
+    x = np.concatenate([np.exp2(-u / y) * rng.choice([1.0, -1.0], 30000),
+                        [5e-324, 1e-310, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf, -np.inf, -0.0, 0.0] * 2])
+    y = np.concatenate([y, [2.0] * 8 + [5.0] * 8])
+    _, _, p = native.arith_probe(x, y)
+    ref = np.array([O.zig_pow(u, v) for u, v in zip(x, y)])
+    assert np.count_nonzero((ref != 0) & (np.abs(ref) < 2.3e-308)) > 5000  # the band is really sampled
+    assert_identical(p.view(np.uint64), ref.view(np.uint64), "pow (subnormal results, thresholds)")
     x = rng.uniform(1e-6, 1, 4000)
     y = rng.choice([10.5, 2.25, 0.5, 12.5, 7.75, 0.3], 4000)
     _, _, p = native.arith_probe(x, y)
