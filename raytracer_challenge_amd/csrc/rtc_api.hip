@@ -815,7 +815,11 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         d.refractive_index = m.refractive_index;
         d.geo = s.geo;
         d.pattern = -1;
-        d.shininess_n = (m.shininess >= 1.0 && m.shininess < 500.0 && m.shininess == std::floor(m.shininess))
+        // (with a light intensity that is not finite a specular term scaled by zero is NaN, not
+        // nothing: such scenes take the general routine, which leaves out no term)
+        const bool finite_light = std::isfinite(light->intensity[0]) && std::isfinite(light->intensity[1]) &&
+                                  std::isfinite(light->intensity[2]);
+        d.shininess_n = (finite_light && m.shininess >= 1.0 && m.shininess < 500.0 && m.shininess == std::floor(m.shininess))
                             ? (int32_t)m.shininess
                             : 0;
         if (m.has_pattern) {

@@ -1088,7 +1088,10 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     const double two_ln = 2.0 * dot3(nl, normalv);
                     const V3 lr = {nl.x - two_ln * normalv.x, nl.y - two_ln * normalv.y, nl.z - two_ln * normalv.z};
                     const double reflect_dot_eye = dot3(lr, eyev);
-                    if (reflect_dot_eye > 0.0) {
+                    // specular == 0 scales a finite power (base at most 2, exponent below 500) to
+                    // zero, and adding that zero changes no value: the power is not evaluated
+                    const bool no_specular = m_specular == 0.0 && m_shininess_n > 0 && reflect_dot_eye <= 2.0;
+                    if (reflect_dot_eye > 0.0 && !no_specular) {
                         const double pw = m_shininess_n > 0
                                               ? pow_small_integer(reflect_dot_eye, m_shininess_n)
                                               : zig_pow(reflect_dot_eye, m_shininess);

@@ -360,6 +360,18 @@ def test_ragged_canvas_sizes(size):
     assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.STREAMING), f"canvas {size}")
 
 
+def test_zero_specular_and_a_light_that_is_not_finite():
+    """The device leaves out the specular power where specular == 0 scales it to zero; with an
+    infinite light intensity that zero times infinity is NaN in the reference and must stay so."""
+    w, c = scenes.draw_world_scene(64, 32)
+    for intensity in (Color(1, 1, 1), Color(math.inf, 1, 1), Color(1, math.nan, 1)):
+        w.light = PointLight(w.light.position, intensity)
+        cpu = O.render(w, c, 3, O.STREAMING)
+        with scene_of(w) as sc:
+            assert_identical(sc.render(c.desc(), 3), cpu, f"light {intensity}")
+    assert np.isnan(cpu).any()
+
+
 def test_empty_world_is_black():  # calc.zig:649-651
     w = World()
     c = default_camera(16)
