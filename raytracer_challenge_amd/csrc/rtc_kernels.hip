@@ -742,6 +742,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     int f_meta[kDeep];
     double f_ray[MAXD][6];
     double f_transp[MAXD], f_R[MAXD];
+#pragma unroll
+    for (int f = 0; f < MAXD; ++f) f_transp[f] = f_R[f] = 0.0;  // read (and not used) for frames that never set them
     auto frame_meta = [&](int f) -> int { return f < kLdsFrames ? frames.meta[f][tid] : f_meta[f - kLdsFrames]; };
     auto set_frame_meta = [&](int f, int v) {
         if (f < kLdsFrames)
@@ -1190,38 +1192,33 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 if (!settled && sp == L + 1) {
                     const int flags = frame_meta(L);
                     const V3 acc0 = frame_acc(L);
-                    if (!(flags & kWaitRefract)) {
-                        // reflected child returned: color.scale(reflective) [.scale(reflectance)]
-                        const double kr = shade_of(flags >> kMetaShapeShift).reflective;
-                        V3 c = {kr * ret.x, kr * ret.y, kr * ret.z};
-                        if (flags & kSchlick) {
-                            const double fR = f_R[L];
-                            c = {fR * c.x, fR * c.y, fR * c.z};
-                        }
-                        const V3 acc = {acc0.x + c.x, acc0.y + c.y, acc0.z + c.z};
-                        if (flags & kHasRefract) {
-                            set_frame_acc(L, acc);
-                            set_frame_meta(L, flags | kWaitRefract);
-                            if (flags & kOutsourced) {
-                                aux = (aux & ~63) | kAuxWaiting | ((flags >> kMetaPartnerShift) & 63);
-                            } else {
-                                ro = {f_ray[L][0], f_ray[L][1], f_ray[L][2]};
-                                rd = {f_ray[L][3], f_ray[L][4], f_ray[L][5]};
-                            }
-                            settled = true;
+                    // The returned child is the reflected one (color.scale(reflective), then
+                    // .scale(reflectance) under Schlick: calc.zig:958,466) or, when the frame was
+                    // waiting for it, the refracted one (color.scale(transparency), then
+                    // .scale(1 - reflectance): calc.zig:852,466): one factor or two, then the sum.
+                    const bool refracted_back = (flags & kWaitRefract) != 0;
+                    const double k_reflect = shade_of(flags >> kMetaShapeShift).reflective;
+                    const double k_child = refracted_back ? f_transp[L] : k_reflect;
+                    V3 c = {k_child * ret.x, k_child * ret.y, k_child * ret.z};
+                    if (flags & kSchlick) {
+                        const double fR = f_R[L];
+                        const double share = refracted_back ? 1.0 - fR : fR;
+                        c = {share * c.x, share * c.y, share * c.z};
+                    }
+                    const V3 acc = {acc0.x + c.x, acc0.y + c.y, acc0.z + c.z};
+                    if (!refracted_back && (flags & kHasRefract)) {
+                        // the refracted subtree is next
+                        set_frame_acc(L, acc);
+                        set_frame_meta(L, flags | kWaitRefract);
+                        if (flags & kOutsourced) {
+                            aux = (aux & ~63) | kAuxWaiting | ((flags >> kMetaPartnerShift) & 63);
                         } else {
-                            ret = acc;  // + Black refracted term
-                            sp = L;
+                            ro = {f_ray[L][0], f_ray[L][1], f_ray[L][2]};
+                            rd = {f_ray[L][3], f_ray[L][4], f_ray[L][5]};
                         }
+                        settled = true;
                     } else {
-                        // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
-                        const double kt = f_transp[L];
-                        V3 c = {kt * ret.x, kt * ret.y, kt * ret.z};
-                        if (flags & kSchlick) {
-                            const double T = 1.0 - f_R[L];
-                            c = {T * c.x, T * c.y, T * c.z};
-                        }
-                        ret = {acc0.x + c.x, acc0.y + c.y, acc0.z + c.z};
+                        ret = acc;  // the frame is complete (a missing refracted term is Black)
                         sp = L;
                     }
                 }
