@@ -815,6 +815,18 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         d.refractive_index = m.refractive_index;
         d.geo = s.geo;
         d.pattern = -1;
+        {
+            // inverse-transpose times the local normal (0,1,0), w forced to 0, normalised by
+            // division (shape.zig:91-96, vector.zig:88-97), products with the zeros included
+            const double* M = full;
+            const double nx = (M[0] * 0.0 + M[4] * 1.0) + M[8] * 0.0;
+            const double ny = (M[1] * 0.0 + M[5] * 1.0) + M[9] * 0.0;
+            const double nz = (M[2] * 0.0 + M[6] * 1.0) + M[10] * 0.0;
+            const double len = std::sqrt((nx * nx + ny * ny) + nz * nz);
+            d.plane_normal[0] = nx / len;
+            d.plane_normal[1] = ny / len;
+            d.plane_normal[2] = nz / len;
+        }
         // (with a light intensity that is not finite a specular term scaled by zero is NaN, not
         // nothing: such scenes take the general routine, which leaves out no term)
         const bool finite_light = std::isfinite(light->intensity[0]) && std::isfinite(light->intensity[1]) &&

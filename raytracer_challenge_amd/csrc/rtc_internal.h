@@ -34,6 +34,9 @@ struct DevShade {
     double pat_a[3];
     double pat_b[3];
     double pat_inv[12];  // rows 0..2 of inverse(pattern.transform), row-major 3x4
+    // Planes: Shape.normalAt (shape.zig:84-97) before the flip towards the eye.  It is the same
+    // vector at every point of a plane, evaluated once on the host with the same operations.
+    double plane_normal[3];
     int32_t geo;         // RTC_GEO_*
     int32_t pattern;     // RTC_PATTERN_* or -1 when the material has no pattern
     int32_t shininess_n; // shininess when it is an integer in [1, 500), else 0 (see pow_small_integer)

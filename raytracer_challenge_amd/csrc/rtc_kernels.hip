@@ -1022,26 +1022,27 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 hit.idx &= ~kExitOpenBit;
                 const DevShade& sh = shade_of(hit.idx);
                 const double* __restrict__ oinv = inverse_of(hit.idx);
-                // gather what the normal needs in one batch (the loads overlap each other)
-                double M[12];
-#pragma unroll
-                for (int q = 0; q < 11; ++q) M[q] = oinv[q];
-                M[11] = oinv[11];
                 const int geo = sh.geo;
 
                 // ---- calc.prepareComputations (calc.zig:247-306)
                 const V3 point = {ro.x + hit.t * rd.x, ro.y + hit.t * rd.y, ro.z + hit.t * rd.z};
                 const V3 eyev = {-rd.x, -rd.y, -rd.z};
                 // Shape.normalAt (shape.zig:84-97)
-                V3 ln;
+                V3 normalv;
                 if (geo == RTC_GEO_SPHERE) {
-                    ln = normalize3(xform_point(M, point));
+                    // gather what the normal needs in one batch (the loads overlap each other)
+                    double M[12];
+#pragma unroll
+                    for (int q = 0; q < 11; ++q) M[q] = oinv[q];
+                    M[11] = oinv[11];
+                    const V3 ln = normalize3(xform_point(M, point));
+                    normalv = normalize3(V3{(M[0] * ln.x + M[4] * ln.y) + M[8] * ln.z,
+                                            (M[1] * ln.x + M[5] * ln.y) + M[9] * ln.z,
+                                            (M[2] * ln.x + M[6] * ln.y) + M[10] * ln.z});
                 } else {
-                    ln = {0.0, 1.0, 0.0};
+                    // a plane's normal does not depend on the point: evaluated at upload
+                    normalv = {sh.plane_normal[0], sh.plane_normal[1], sh.plane_normal[2]};
                 }
-                V3 normalv = normalize3(V3{(M[0] * ln.x + M[4] * ln.y) + M[8] * ln.z,
-                                           (M[1] * ln.x + M[5] * ln.y) + M[9] * ln.z,
-                                           (M[2] * ln.x + M[6] * ln.y) + M[10] * ln.z});
                 if (dot3(normalv, eyev) < 0) normalv = {-normalv.x, -normalv.y, -normalv.z};
                 const V3 offs = {kSurfaceEps * normalv.x, kSurfaceEps * normalv.y, kSurfaceEps * normalv.z};
                 const V3 over_point = {point.x + offs.x, point.y + offs.y, point.z + offs.z};
