@@ -691,6 +691,34 @@ struct HotTables<true> {
 };
 static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
 
+// The by-value kernel arguments hold some sixty scalars (camera, light) that the loop needs at a
+// few places only.  Kept in registers over the whole loop they do not fit the scalar file, and
+// the allocator parks them in lanes of vector registers: every use then costs a vector
+// instruction (v_readlane) per 32 bits.  Reading them from the kernel-argument segment where
+// they are used costs a few scalar loads instead (the segment stays in the scalar cache); the
+// empty asm makes the address opaque, so that the loads are not hoisted out of the loop again.
+// Layout of the segment: the eight pointers, then DevWorld, then DevJob (checked against the
+// code object's metadata by the build's assembly listing).
+constexpr int kWorldArgOffset = 8 * 8;
+constexpr int kJobArgOffset = kWorldArgOffset + (int)sizeof(DevWorld);
+static_assert(sizeof(DevWorld) % 8 == 0 && alignof(DevJob) == 8 && alignof(DevWorld) == 8, "kernel-argument layout");
+typedef const __attribute__((address_space(4))) DevJob* JobArg;
+typedef const __attribute__((address_space(4))) DevWorld* WorldArg;
+__device__ __forceinline__ JobArg job_argument() {
+    const __attribute__((address_space(4))) char* base =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    JobArg j = (JobArg)(base + kJobArgOffset);
+    asm volatile("" : "+s"(j));
+    return j;
+}
+__device__ __forceinline__ WorldArg world_argument() {
+    const __attribute__((address_space(4))) char* base =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    WorldArg w = (WorldArg)(base + kWorldArgOffset);
+    asm volatile("" : "+s"(w));
+    return w;
+}
+
 // The read-only tables and the output are separate __restrict__ kernel arguments so that
 // the compiler can prove the wave-uniform table reads are never clobbered by the kernel's
 // own stores and keep them on the scalar path; the structs carry the remaining scalars.
@@ -798,11 +826,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     uint32_t blk_base = 0, blk_px0 = 0, blk_py0 = 0;
     bool blk_valid = false;
     uint32_t blk_out0 = 0;
-    // inverse(camera.transform) * point(0,0,0) (camera.zig:60): the same value for every pixel,
-    // evaluated once on the host with the same expression
-    const V3 cam_origin = {job.cam_origin[0], job.cam_origin[1], job.cam_origin[2]};
-    const V3 light = {w.light_pos[0], w.light_pos[1], w.light_pos[2]};
-    const V3 lint = {w.light_int[0], w.light_int[1], w.light_int[2]};
+    // (job.cam_origin is inverse(camera.transform) * point(0,0,0) (camera.zig:60): the same value
+    // for every pixel, evaluated once on the host with the same expression)
 
 #ifdef RTC_PROBE
     const unsigned long long probe_t0 = wall_clock64();
@@ -897,11 +922,16 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     const uint32_t px = blk_px0 + tx, py = blk_py0 + ty;
                     if (blk_valid && px < job.hsize && py < job.vsize) {
                         // Camera.rayForPixel (camera.zig:48-72)
-                        const double x_offset = ((double)px + 0.5) * job.pixel_size;
-                        const double y_offset = ((double)py + 0.5) * job.pixel_size;
-                        const double world_x = job.half_width - x_offset;
-                        const double world_y = job.half_height - y_offset;
-                        const V3 pixel = xform_point(job.cam_inv, V3{world_x, world_y, -1.0});
+                        const JobArg ja = job_argument();
+                        double cam_inv[12];
+#pragma unroll
+                        for (int q = 0; q < 12; ++q) cam_inv[q] = ja->cam_inv[q];
+                        const V3 cam_origin = {ja->cam_origin[0], ja->cam_origin[1], ja->cam_origin[2]};
+                        const double x_offset = ((double)px + 0.5) * ja->pixel_size;
+                        const double y_offset = ((double)py + 0.5) * ja->pixel_size;
+                        const double world_x = ja->half_width - x_offset;
+                        const double world_y = ja->half_height - y_offset;
+                        const V3 pixel = xform_point(cam_inv, V3{world_x, world_y, -1.0});
                         ro = cam_origin;
                         rd = normalize3(V3{pixel.x - cam_origin.x, pixel.y - cam_origin.y, pixel.z - cam_origin.z});
                         const uint32_t row_stride = job.tile_ranks == 1 ? job.hsize : (uint32_t)RTC_TILE_W;
@@ -1049,6 +1079,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 
                 // ---- calc.isShadowed (calc.zig:777-790) at over_point
                 if (STATS) ++n_shadow;
+                const WorldArg wa = world_argument();
+                const V3 light = {wa->light_pos[0], wa->light_pos[1], wa->light_pos[2]};
                 const V3 lv = {light.x - over_point.x, light.y - over_point.y, light.z - over_point.z};
                 const double distance = sqrt((lv.x * lv.x + lv.y * lv.y) + lv.z * lv.z);
                 const V3 lightv = {lv.x / distance, lv.y / distance, lv.z / distance};
@@ -1081,6 +1113,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 // light.position.sub(position).normalize() the reference recomputes
                 if (m_pattern >= 0) color = pattern_color(sh, oinv, over_point);
                 RTC_STAMP(pc_pattern);
+                const WorldArg wl = world_argument();
+                const V3 lint = {wl->light_int[0], wl->light_int[1], wl->light_int[2]};
                 const V3 eff = {color.x * lint.x, color.y * lint.y, color.z * lint.z};
                 V3 surface = {m_ambient * eff.x, m_ambient * eff.y, m_ambient * eff.z};
                 const double light_dot_normal = dot3(lightv, normalv);
