@@ -254,6 +254,7 @@ rtc::DevWorld dev_world(const RtcScene* s) {
         w.light_pos[i] = s->light_pos[i];
         w.light_int[i] = s->light_int[i];
     }
+    w.light_reach = ((std::fabs(s->light_pos[0]) + std::fabs(s->light_pos[1])) + std::fabs(s->light_pos[2])) + 1.0;
     return w;
 }
 
@@ -625,6 +626,22 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
     return RTC_OK;
 }
 
+// What the shadow sweep's same-side test needs of a plane (see sweep_shape): the sign and size of
+// the light's local y, and the guard factor; {0, 0, inf} switches the test off for the plane.
+void plane_light_side(const double* inv12, const double* light_pos, double out[3]) {
+    const double m4 = inv12[4], m5 = inv12[5], m6 = inv12[6], m7 = inv12[7];
+    const double h = ((m4 * light_pos[0] + m5 * light_pos[1]) + m6 * light_pos[2]) + m7;
+    const double guard = 0x1p-32 * std::fmax((std::fabs(m4) + std::fabs(m5)) + std::fabs(m6), std::fabs(m7));
+    out[0] = h > 0 ? 1.0 : (h < 0 ? -1.0 : 0.0);
+    out[1] = std::fabs(h);
+    out[2] = guard;
+    if (!std::isfinite(h) || !std::isfinite(guard)) {
+        out[0] = 0.0;
+        out[1] = 0.0;
+        out[2] = std::numeric_limits<double>::infinity();
+    }
+}
+
 // Device canvas -> the caller's (pageable, usually freshly allocated) buffer.  A plain hipMemcpy
 // into such memory runs at 10-17 GB/s on this platform (staging inside the runtime plus the first
 // touch of every page) against 57 GB/s into pinned memory.  Large canvases therefore go through a
@@ -882,6 +899,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 const int64_t order_word = (int64_t)i;
                 std::memcpy(&tab[pos * kRec + 12], &order_word, sizeof order_word);
                 sphere_bound(shapes[i], &inv12[i * 12], &tab[pos * kRec + 13]);
+                if (shapes[i].geo == RTC_GEO_PLANE) plane_light_side(&inv12[i * 12], light->position, &tab[pos * kRec + 17]);
                 if (shapes[i].geo == RTC_GEO_SPHERE) {
                     RtcScene::SphereBound sb;
                     std::memcpy(sb.b, &tab[pos * kRec + 13], sizeof sb.b);

@@ -53,7 +53,8 @@ struct DevShade {
 //           inverse(shape.transform), row-major 3x4; [12] the shape's index in the reference's
 //           list (an integer in the low bits of the word); [13..15] centre and [16] enlarged
 //           squared radius of a world-space bounding sphere (spheres only; +inf = none);
-//           [17..19] padding.  The sweep reads it with wave-uniform addresses, up to two
+//           [17..19] planes only: side of the plane the light is on (+1, -1, 0 = unknown),
+//           |local y of the light|, guard factor 2^-32 max(|m4|+|m5|+|m6|, |m7|).  The sweep reads it with wave-uniform addresses, up to two
 //           records ahead, hence two padding records.
 //   shade : n x DevShade, table order — gathered per lane at a hit.
 //   order : n x int32, table position -> list index (tie-breaks between equal t).
@@ -80,6 +81,7 @@ struct DevWorld {
     double bvh_origin_limit; // rays starting farther out than this (any coordinate) are not pruned
     double light_pos[3];
     double light_int[3];
+    double light_reach;  // 1 + |x| + |y| + |z| of the light position (see the same-side test of the plane sweep)
 };
 
 // Work description of one launch.

@@ -296,6 +296,9 @@ struct ShapeRec {
     long long order;  // index of the shape in the reference's list (world.objects)
     double bc[3];     // spheres: centre of a world-space bounding sphere ...
     double br2;       // ... and its squared radius, enlarged by the error margin (+inf: no bound)
+    // planes: on which side of the plane the light lies (+1 / -1; 0 = unknown), how far (the
+    // local y of the light, absolute value), and the guard factor of the same-side test below
+    double light_side, light_height, side_guard;
 };
 // Wave-uniform read of the record at table position i (scalar loads); the table ends with
 // padding records so that reading ahead is always in bounds.
@@ -309,6 +312,9 @@ __device__ __forceinline__ ShapeRec load_rec(const double* __restrict__ tab, int
     r.bc[1] = p[14];
     r.bc[2] = p[15];
     r.br2 = p[16];
+    r.light_side = p[17];
+    r.light_height = p[18];
+    r.side_guard = p[19];
     return r;
 }
 
@@ -333,8 +339,8 @@ enum : int { kSphereAxis = 0, kSphereGeneral = 1, kPlaneAxis = 2, kPlaneGeneral 
 // are equal.
 template <int KIND, bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const int* __restrict__ order_of,
-                                            const V3& o, const V3& d, double dd, Sweep& s, ContainerSlots& cs,
-                                            SweepCounters& ctr) {
+                                            const V3& o, const V3& d, double dd, double side_scale, Sweep& s,
+                                            ContainerSlots& cs, SweepCounters& ctr) {
     const double* m = rec.m;
     const int tid = (int)threadIdx.x;
     // What this shape contributes, decided inside the branches below; the sweep state itself
@@ -405,11 +411,28 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
         // Plane.localIntersect (shape.zig:55-70): only row 1 of the local ray is used
         double loy, ldy;
         if (KIND == kPlaneAxis) {  // m[4] and m[6] are exact zeros
-            ldy = m[5] * d.y;
             loy = m[5] * o.y + m[7];
         } else {
-            ldy = (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
             loy = ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7];
+        }
+        // A shadow ray ends at the light.  When its origin and the light lie on the same side of
+        // the plane, both farther from it than 2^-32 of the magnitudes involved, the line meets
+        // the plane behind the origin or beyond the light: with heights h0 (origin) and h1 (light)
+        // of equal sign, t = h0 * dist / (h0 - h1) exceeds dist by the factor 1 + h1/(h0 - h1) when
+        // the ray descends, and is negative when it climbs; the reference's rounding moves t and
+        // dist by parts in 2^50, the guard is parts in 2^32 (and a direction whose rounded local
+        // y has the wrong sign is so flat that |t| is 2^16 times the distance; the surface offset
+        // of 1e-4 that lifts a ray's origin off the plane it starts on stays well above the guard).  Such a plane
+        // cannot make calc.isShadowed true and nothing more of it is evaluated.  The statistics
+        // build counts the reference's intersections and evaluates every plane.
+        if (SHADOW && !STATS) {
+            const double guard = rec.side_guard * side_scale;
+            if (loy * rec.light_side > guard && rec.light_height > guard) return;
+        }
+        if (KIND == kPlaneAxis) {
+            ldy = m[5] * d.y;
+        } else {
+            ldy = (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
         }
         const bool hits = !(fabs(ldy) < kF64Eps);
         if (STATS && hits) ++ctr.plane_hits;
@@ -460,17 +483,17 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
 // arithmetic.  The two record buffers alternate, so no register copies are needed.
 template <int KIND, bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, const int* __restrict__ order_of, int begin,
-                                            int end, const V3& o, const V3& d, double dd, Sweep& s, ContainerSlots& cs,
-                                            SweepCounters& ctr) {
+                                            int end, const V3& o, const V3& d, double dd, double side_scale, Sweep& s,
+                                            ContainerSlots& cs, SweepCounters& ctr) {
     if (begin >= end) return;
     ShapeRec A = load_rec(tab, begin);
     for (int i = begin; i < end; i += 2) {
         asm volatile("" ::"s"(A.order) : "memory");
         const ShapeRec B = load_rec(tab, i + 1);
-        sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, dd, s, cs, ctr);
+        sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, dd, side_scale, s, cs, ctr);
         asm volatile("" ::"s"(B.order) : "memory");
         A = load_rec(tab, i + 2);
-        if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, dd, s, cs, ctr);
+        if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, dd, side_scale, s, cs, ctr);
     }
 }
 
@@ -502,9 +525,9 @@ __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab
             const ShapeRec rec = load_rec(tab, pos);
             // the table keeps the spheres with a diagonal inverse first: they need six of the twelve entries
             if (pos < w.group[1])
-                sweep_shape<kSphereAxis, SHADOW, STATS>(rec, pos, order_of, o, d, dd, s, cs, ctr);
+                sweep_shape<kSphereAxis, SHADOW, STATS>(rec, pos, order_of, o, d, dd, 0.0, s, cs, ctr);
             else
-                sweep_shape<kSphereGeneral, SHADOW, STATS>(rec, pos, order_of, o, d, dd, s, cs, ctr);
+                sweep_shape<kSphereGeneral, SHADOW, STATS>(rec, pos, order_of, o, d, dd, 0.0, s, cs, ctr);
             if (SHADOW && s.idx >= 0) break;  // calc.isShadowed only asks whether anything is in the way
         } else {
             const BvhNode* __restrict__ n = w.bvh + cur;
@@ -561,6 +584,8 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
                                             SweepCounters& ctr) {
     const int tid = (int)threadIdx.x;
     const double dd = fma(d.z, d.z, fma(d.y, d.y, d.x * d.x));  // for the bounding-sphere tests
+    // for the same-side test of the planes: 1 + |o|_1 + |light|_1 bounds every magnitude in it
+    const double side_scale = SHADOW ? ((fabs(o.x) + fabs(o.y)) + fabs(o.z)) + w.light_reach : 0.0;
     s.idx = -1;
 #ifdef RTC_PROBE
     const uint32_t lane_full0 = ctr.lane_full, wave_full0 = ctr.wave_full;
@@ -570,13 +595,13 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
         cs.i[0][tid] = -1;
         cs.i[1][tid] = -1;
     }
-    sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, dd, s, cs, ctr);
-    sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, dd, s, cs, ctr);
+    sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, dd, side_scale, s, cs, ctr);
+    sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, dd, side_scale, s, cs, ctr);
     if (ACCEL) {
         if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, s, cs, ctr);
     } else {
-        sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, s, cs, ctr);
-        sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, s, cs, ctr);
+        sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, side_scale, s, cs, ctr);
+        sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, side_scale, s, cs, ctr);
     }
 #ifdef RTC_PROBE
     {

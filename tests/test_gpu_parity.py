@@ -360,6 +360,37 @@ def test_ragged_canvas_sizes(size):
     assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.STREAMING), f"canvas {size}")
 
 
+@pytest.mark.parametrize("light_height", [3.0, 1e-3, 1e-7, 1e-11, 0.0, -1e-7])
+def test_shadow_rays_that_start_or_end_close_to_a_plane(light_height):
+    """The shadow sweep leaves a plane out when the ray's origin and the light are clearly on the
+    same side of it.  Hits within 1e-13 ... 1e-2 of the line where two walls and the floor meet,
+    and a light that hovers just above (or lies in, or just below) the floor, are where "clearly"
+    is decided; scaled and translated planes make the magnitudes uneven."""
+    rng = np.random.default_rng(5)
+    w = World()
+    w.light = PointLight(init_point(1.5, light_height, -2.0), Color(1, 1, 1))
+    floor = Shape("plane", Mat4.identity(), Material(color=Color(0.9, 0.8, 0.7), reflective=0.3))
+    wall = Shape("plane", Mat4.identity().rotate_x(math.pi / 2).translate(0, 0, 4),
+                 Material(color=Color(0.6, 0.8, 0.9), specular=0.0))
+    side = Shape("plane", Mat4.identity().scale(3, 0.01, 3).rotate_z(math.pi / 2).translate(-300.25, 0, 0),
+                 Material(color=Color(0.7, 0.9, 0.6)))
+    tilted = Shape("plane", Mat4.identity().rotate_z(1e-6).translate(0, -1e-9, 0), Material(color=Color(0.5, 0.5, 0.9)))
+    ball = Shape("sphere", Mat4.identity().scale(0.5, 0.5, 0.5).translate(0.3, 0.5, 1.0), Material(reflective=0.2))
+    w.objects += [floor, wall, side, tilted, ball]
+    n = 4000
+    rays = np.empty((n, 6))
+    for k in range(n):
+        eps = 10.0 ** rng.uniform(-13, -2) * (1 if k % 3 else 0)
+        # a point on the floor close to the back wall, or on the back wall close to the floor
+        target = np.array([rng.uniform(-3, 3), 0.0, 4.0 - eps]) if k % 2 else np.array([rng.uniform(-3, 3), eps, 4.0])
+        eye = np.array([rng.uniform(-2, 2), rng.uniform(0.5, 3), rng.uniform(-6, -3)])
+        rays[k, :3] = eye
+        rays[k, 3:] = (target - eye) / np.linalg.norm(target - eye)
+    cpu = O.color_at(w, rays, 4, O.STREAMING)
+    with scene_of(w) as sc:
+        assert_identical(sc.color_at(rays, 4), cpu, f"light {light_height} above the floor")
+
+
 def test_zero_specular_and_a_light_that_is_not_finite():
     """The device leaves out the specular power where specular == 0 scales it to zero; with an
     infinite light intensity that zero times infinity is NaN in the reference and must stay so."""
