@@ -62,14 +62,17 @@ def executed_flops(st, groups):
     skip the products with those zeros (values unchanged): 30 instead of 54 per ray-sphere test,
     3 instead of 11 per ray-plane test; every ray-sphere pair first pays 17 flops for the
     bounding-sphere test (5 more per sweep), and the pairs it dismisses pay nothing else (the
-    dismissed pairs are taken as spread evenly over the two sphere groups).  Root filters and
-    bookkeeping compares are not counted."""
+    dismissed pairs are taken as spread evenly over the two sphere groups); a plane that a shadow
+    ray's origin shares a side of with the light costs its origin row only (2 of 3, or 6 of 11
+    flops; taken as spread evenly over the two plane groups).  Root filters and bookkeeping
+    compares are not counted."""
     rays = st["radiance_rays"] + st["shadow_rays"]
     s_axis, s_gen, p_axis, p_gen = groups
     n_s = s_axis + s_gen
     kept = 1.0 - st["sphere_bound_skips"] / max(st["sphere_tests"], 1)
+    side = st["plane_side_skips"] / max(st["plane_tests"], 1)
     return (
-        rays * (5 + 17 * n_s + kept * (30 * s_axis + 54 * s_gen) + 3 * p_axis + 11 * p_gen)
+        rays * (5 + 17 * n_s + kept * (30 * s_axis + 54 * s_gen) + (3 - side) * p_axis + (11 - 5 * side) * p_gen)
         + FLOPS_SPHERE_HIT * st["sphere_hits"]
         + FLOPS_PLANE_HIT * st["plane_hits"]
         + FLOPS_SHADED_HIT * st["shaded_hits"]
@@ -251,13 +254,13 @@ def main():
     scene.render_device(cam, args.depth, local.data_ptr(), rank, world_size, stream, st)
     counts = torch.tensor(
         [st.radiance_rays, st.shadow_rays, st.sphere_tests, st.plane_tests, st.sphere_hits, st.plane_hits,
-         st.shaded_hits, st.sphere_bound_skips],
+         st.shaded_hits, st.sphere_bound_skips, st.plane_side_skips],
         dtype=torch.int64, device=dev,
     )
     if world_size > 1:
         dist.all_reduce(counts)
     names = ["radiance_rays", "shadow_rays", "sphere_tests", "plane_tests", "sphere_hits", "plane_hits", "shaded_hits",
-             "sphere_bound_skips"]
+             "sphere_bound_skips", "plane_side_skips"]
     total = dict(zip(names, (int(v) for v in counts.tolist())))
     local_flops = algorithmic_flops(st.as_dict())
     local_executed = executed_flops(st.as_dict(), scene.group_counts())

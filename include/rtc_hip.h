@@ -108,7 +108,9 @@ typedef struct RtcCameraDesc {
  * render kernel measured with HIP events on the stream it ran on.  sphere_bound_skips counts
  * the (ray, sphere) pairs (part of sphere_tests) that the library dismissed with its bounding
  * sphere test without evaluating the reference's 54-flop intersection: their discriminant
- * would have been negative. */
+ * would have been negative.  plane_side_skips counts the (shadow ray, plane) pairs (part of
+ * plane_tests) of which only the origin's row is evaluated, because origin and light lie
+ * clearly on the same side of the plane. */
 typedef struct RtcStats {
     uint64_t radiance_rays;
     uint64_t shadow_rays;
@@ -120,6 +122,7 @@ typedef struct RtcStats {
     uint64_t pixels;
     double kernel_ms;
     uint64_t sphere_bound_skips;
+    uint64_t plane_side_skips;
 } RtcStats;
 
 /* Opaque handle of an uploaded world (World, world.zig:15-28). */

@@ -71,6 +71,7 @@ void fillStats(const orc::Stats& s, RtcStats* out, uint64_t pixels, double ms) {
     out->pixels = pixels;
     out->kernel_ms = ms;
     out->sphere_bound_skips = 0;  // the reference evaluates every pair
+    out->plane_side_skips = 0;
 }
 
 }  // namespace

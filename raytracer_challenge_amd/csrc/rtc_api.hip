@@ -278,7 +278,7 @@ int check_camera(const RtcCameraDesc* c) {
 
 // Fill stats from the device counters (after the stream has been synchronised).
 int read_stats(RtcScene* s, RtcStats* out, uint64_t pixels, float ms) {
-    uint64_t h[6];
+    uint64_t h[7];
     HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
     out->radiance_rays = h[0];
     out->shadow_rays = h[1];
@@ -288,6 +288,7 @@ int read_stats(RtcScene* s, RtcStats* out, uint64_t pixels, float ms) {
     out->plane_hits = h[3];
     out->shaded_hits = h[4];
     out->sphere_bound_skips = h[5];
+    out->plane_side_skips = h[6];
     out->pixels = pixels;
     out->kernel_ms = ms;
     return RTC_OK;

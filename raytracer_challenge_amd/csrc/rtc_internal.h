@@ -102,7 +102,7 @@ struct DevJob {
     int32_t depth;
     double* out;
     uint32_t* counter;  // control block: the work-queue heads first, zeroed before the launch
-    uint64_t* stats;    // 5 counters (radiance, shadow, sphere hits, plane hits, shaded) or nullptr
+    uint64_t* stats;    // 7 counters (radiance, shadow, sphere hits, plane hits, shaded, sphere skips, plane skips) or nullptr
 };
 
 // Launchers implemented in rtc_kernels.hip.  grid_blocks == 0 lets the launcher size the

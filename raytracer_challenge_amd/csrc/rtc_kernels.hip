@@ -280,7 +280,7 @@ constexpr double kOnePlus = 1.0 + 0x1p-40;
 // STATS builds only: (ray, shape) pairs whose local intersect produced roots, and pairs the
 // bounding-sphere test dismissed.
 struct SweepCounters {
-    uint32_t sphere_hits, plane_hits, sphere_skips;
+    uint32_t sphere_hits, plane_hits, sphere_skips, plane_skips;
 #ifdef RTC_PROBE
     uint32_t wave_full, lane_full;
 #endif
@@ -425,9 +425,12 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
         // of 1e-4 that lifts a ray's origin off the plane it starts on stays well above the guard).  Such a plane
         // cannot make calc.isShadowed true and nothing more of it is evaluated.  The statistics
         // build counts the reference's intersections and evaluates every plane.
-        if (SHADOW && !STATS) {
+        if (SHADOW) {
             const double guard = rec.side_guard * side_scale;
-            if (loy * rec.light_side > guard && rec.light_height > guard) return;
+            if (loy * rec.light_side > guard && rec.light_height > guard) {
+                if (!STATS) return;
+                ++ctr.plane_skips;
+            }
         }
         if (KIND == kPlaneAxis) {
             ldy = m[5] * d.y;
@@ -1319,8 +1322,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
     if (STATS) {
         // one atomic per counter per wave
-        uint32_t v[6] = {n_radiance, n_shadow, ctr.sphere_hits, ctr.plane_hits, n_shaded, ctr.sphere_skips};
-        for (int c = 0; c < 6; ++c) {
+        uint32_t v[7] = {n_radiance, n_shadow, ctr.sphere_hits, ctr.plane_hits, n_shaded, ctr.sphere_skips, ctr.plane_skips};
+        for (int c = 0; c < 7; ++c) {
             unsigned long long sum = v[c];
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
             if (lane == 0) atomicAdd(&g_stats[c], sum);

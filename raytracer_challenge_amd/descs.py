@@ -95,6 +95,7 @@ class RtcStats(C.Structure):
         ("pixels", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("sphere_bound_skips", C.c_uint64),
+        ("plane_side_skips", C.c_uint64),
     ]
 
     def as_dict(self):
