@@ -281,15 +281,7 @@ constexpr double kOnePlus = 1.0 + 0x1p-40;
 // bounding-sphere test dismissed.
 struct SweepCounters {
     uint32_t sphere_hits, plane_hits, sphere_skips, plane_skips;
-#ifdef RTC_PROBE
-    uint32_t wave_full, lane_full;
-#endif
 };
-#ifdef RTC_PROBE
-// per wave of the block: sweeps, full sphere tests the wave executed, sum over sweeps of the
-// largest number of full tests a single lane needed, sum of active lanes
-__shared__ unsigned int g_probe_sweeps[4][4];
-#endif
 
 struct ShapeRec {
     double m[12];
@@ -361,10 +353,6 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
         const double oc2 = fma(oc.z, oc.z, fma(oc.y, oc.y, oc.x * oc.x));
         const double apart = fma(oc2, kBoundShrink, -rec.br2) * dd;
         if (STATS && apart > ocd * ocd) ++ctr.sphere_skips;
-#ifdef RTC_PROBE
-        if (__ballot(!(apart > ocd * ocd)) != 0) ++ctr.wave_full;
-        if (!(apart > ocd * ocd)) ++ctr.lane_full;
-#endif
         if (!(apart > ocd * ocd)) {
         // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
         V3 lo, ld;
@@ -450,13 +438,21 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
             const double lim = (s.t * kOnePlus) * (ldy * ldy);
             need = hits && !(p < 0) && !(p > lim);
         }
-        if (need) {
+        if (SHADOW) {
+            if (need) {
+                const double t = -loy / ldy;
+                cand = t;
+                better = t >= 0 && t < s.t;
+            }
+        } else {
+            // no branch around the division: nearly every lane needs it (a quotient that the
+            // reference does not form, |ldy| < epsilon, is computed and not used)
             const double t = -loy / ldy;
+            const bool ahead = hits && t >= 0;
             cand = t;
-            better = t >= 0 && (!have || t < s.t);
-            if (!SHADOW && t >= 0 && s.idx >= 0 && t == s.t)
-                better = (int)rec.order < order_of[s.idx & ~kExitOpenBit];
-            push = t < 0;
+            better = ahead && (s.idx < 0 || t < s.t);
+            if (ahead && s.idx >= 0 && t == s.t) better = (int)rec.order < order_of[s.idx & ~kExitOpenBit];
+            push = hits && t < 0;
             push_t = t;
         }
     }
@@ -590,9 +586,6 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     // for the same-side test of the planes: 1 + |o|_1 + |light|_1 bounds every magnitude in it
     const double side_scale = SHADOW ? ((fabs(o.x) + fabs(o.y)) + fabs(o.z)) + w.light_reach : 0.0;
     s.idx = -1;
-#ifdef RTC_PROBE
-    const uint32_t lane_full0 = ctr.lane_full, wave_full0 = ctr.wave_full;
-#endif
     if (!SHADOW) {
         s.t = 0.0;
         cs.i[0][tid] = -1;
@@ -606,25 +599,6 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
         sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, side_scale, s, cs, ctr);
         sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, side_scale, s, cs, ctr);
     }
-#ifdef RTC_PROBE
-    {
-        uint32_t mx = ctr.lane_full - lane_full0;
-        unsigned long long ex = __ballot(1);
-        uint32_t best = 0;
-        for (int l = 0; l < 64; ++l)
-            if ((ex >> l) & 1) {
-                const uint32_t v = (uint32_t)__shfl((int)mx, l);
-                best = v > best ? v : best;
-            }
-        if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
-            unsigned int* acc = g_probe_sweeps[threadIdx.x >> 6];
-            acc[0] += 1;
-            acc[1] += ctr.wave_full - wave_full0;
-            acc[2] += best;
-            acc[3] += (unsigned)__popcll(ex);
-        }
-    }
-#endif
     if (!SHADOW) {
         s.top1 = cs.i[0][tid];
         s.top2 = cs.i[1][tid];
@@ -861,7 +835,6 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     const unsigned long long probe_t0 = wall_clock64();
     unsigned long long probe_tx = 0;
     unsigned long long pcv[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (lane < 4) g_probe_sweeps[threadIdx.x >> 6][lane] = 0;
     unsigned long long pc_mark = clock64();
     enum { pc_refill, pc_sweep1, pc_prep, pc_sweep2, pc_gather, pc_pattern, pc_light, pc_children, pc_push, pc_unwind, pc_iters = 15 };
 #define RTC_STAMP(acc)                          \
@@ -1316,7 +1289,6 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             pr[wid * 3 + 2] = wall_clock64();
             unsigned long long* pc = pr + 3 * 8192 + wid * 16;
             for (int q = 0; q < 16; ++q) pc[q] = pcv[q];
-            for (int q = 0; q < 4; ++q) pc[10 + q] = g_probe_sweeps[threadIdx.x >> 6][q];
         }
     }
 #endif

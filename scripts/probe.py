@@ -39,6 +39,3 @@ iters = pc[:, 15].sum()
 print("wave-iterations", int(iters), " cycles per wave-iteration %.0f" % (tot / iters))
 for k, nme in enumerate(names):
     print("  %-13s %5.1f%%  %8.0f cycles/iter" % (nme, 100 * pc[:, k].sum() / tot, pc[:, k].sum() / iters))
-sw = pc[:, 10:14].sum(axis=0)
-if sw[0] > 0:
-    print("sweeps %d: full sphere tests executed per sweep %.2f, largest per-lane need %.2f, active lanes %.1f" % (sw[0], sw[1] / sw[0], sw[2] / sw[0], sw[3] / sw[0]))
