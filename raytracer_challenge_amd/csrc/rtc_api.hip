@@ -643,6 +643,26 @@ void plane_light_side(const double* inv12, const double* light_pos, double out[3
     }
 }
 
+// The bounding-sphere test of sphere_bound for a shadow ray, anchored at the light instead of the
+// ray's origin.  The ray o + t d, d = normalize(light - o), dist = |light - o|, passes the light
+// within 2^-51 dist, so the distance between its line and the centre c is the distance of c from
+// the line through the light with direction d, up to that much.  With lc = c - light,
+//     |c - o|^2 <= 2 |lc|^2 + 2 dist^2   and   |d|^2 = 1 +- 2^-50 ,
+// the condition of sphere_bound follows from
+//     |lc|^2 (1 - 2^-25) - bound[3] (1 + 2^-40) - 2^-25 dist^2 > (lc . d)^2 ,
+// whose left side is out[3] minus a per-ray term: three multiply-adds per sphere instead of the
+// origin's nine.  out[0..2] = lc.
+void sphere_from_light(const double* bound, const double* light_pos, double out[4]) {
+    double l2 = 0;
+    for (int a = 0; a < 3; ++a) {
+        out[a] = bound[a] - light_pos[a];
+        l2 += out[a] * out[a];
+    }
+    out[3] = l2 * (1.0 - 0x1p-25) - bound[3] * (1.0 + 0x1p-40);
+    if (!std::isfinite(out[0]) || !std::isfinite(out[1]) || !std::isfinite(out[2]) || !(out[3] == out[3]))
+        out[3] = -std::numeric_limits<double>::infinity();
+}
+
 // Device canvas -> the caller's (pageable, usually freshly allocated) buffer.  A plain hipMemcpy
 // into such memory runs at 10-17 GB/s on this platform (staging inside the runtime plus the first
 // touch of every page) against 57 GB/s into pinned memory.  Large canvases therefore go through a
@@ -901,6 +921,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 std::memcpy(&tab[pos * kRec + 12], &order_word, sizeof order_word);
                 sphere_bound(shapes[i], &inv12[i * 12], &tab[pos * kRec + 13]);
                 if (shapes[i].geo == RTC_GEO_PLANE) plane_light_side(&inv12[i * 12], light->position, &tab[pos * kRec + 17]);
+                if (shapes[i].geo == RTC_GEO_SPHERE) sphere_from_light(&tab[pos * kRec + 13], light->position, &tab[pos * kRec + 20]);
                 if (shapes[i].geo == RTC_GEO_SPHERE) {
                     RtcScene::SphereBound sb;
                     std::memcpy(sb.b, &tab[pos * kRec + 13], sizeof sb.b);

@@ -26,7 +26,7 @@ constexpr int kQueueStrideWords = 32;  // uint32 words between queue heads
 constexpr int kStatsOffsetBytes = kQueues * kQueueStrideWords * 4;
 constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 64;
 
-constexpr int kRecordDoubles = 20;  // doubles per sweep-table record (see DevWorld)
+constexpr int kRecordDoubles = 24;  // doubles per sweep-table record (see DevWorld)
 
 struct DevShade {
     double color[3];
@@ -49,12 +49,14 @@ struct DevShade {
 // The shapes are stored in "table order": four groups (spheres whose inverse is diagonal,
 // other spheres, planes whose inverse row 1 is (0,m,0,t), other planes), each group in the
 // reference's list order.  group[g]..group[g+1] are the table positions of group g.
-//   tab   : (n+2) x 20 doubles, one 160-byte record per shape: [0..11] rows 0..2 of
+//   tab   : (n+2) x 24 doubles, one 192-byte record per shape: [0..11] rows 0..2 of
 //           inverse(shape.transform), row-major 3x4; [12] the shape's index in the reference's
 //           list (an integer in the low bits of the word); [13..15] centre and [16] enlarged
 //           squared radius of a world-space bounding sphere (spheres only; +inf = none);
 //           [17..19] planes only: side of the plane the light is on (+1, -1, 0 = unknown),
-//           |local y of the light|, guard factor 2^-32 max(|m4|+|m5|+|m6|, |m7|).  The sweep reads it with wave-uniform addresses, up to two
+//           |local y of the light|, guard factor 2^-32 max(|m4|+|m5|+|m6|, |m7|);
+//           [20..23] spheres only, for shadow rays (which all end at the light): bounding-sphere
+//           centre minus light position, and |that|^2 (1 - 2^-25) - [16] (1 + 2^-40).  The sweep reads it with wave-uniform addresses, up to two
 //           records ahead, hence two padding records.
 //   shade : n x DevShade, table order — gathered per lane at a hit.
 //   order : n x int32, table position -> list index (tie-breaks between equal t).

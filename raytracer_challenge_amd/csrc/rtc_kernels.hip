@@ -291,6 +291,10 @@ struct ShapeRec {
     // planes: on which side of the plane the light lies (+1 / -1; 0 = unknown), how far (the
     // local y of the light, absolute value), and the guard factor of the same-side test below
     double light_side, light_height, side_guard;
+    // spheres: the bounding-sphere test anchored at the light, for shadow rays (see sphere_from_light
+    // on the host): centre minus light, and the ray-independent part of the test's left side
+    double lc[3];
+    double lk;
 };
 // Wave-uniform read of the record at table position i (scalar loads); the table ends with
 // padding records so that reading ahead is always in bounds.
@@ -307,6 +311,10 @@ __device__ __forceinline__ ShapeRec load_rec(const double* __restrict__ tab, int
     r.light_side = p[17];
     r.light_height = p[18];
     r.side_guard = p[19];
+    r.lc[0] = p[20];
+    r.lc[1] = p[21];
+    r.lc[2] = p[22];
+    r.lk = p[23];
     return r;
 }
 
@@ -331,7 +339,7 @@ enum : int { kSphereAxis = 0, kSphereGeneral = 1, kPlaneAxis = 2, kPlaneGeneral 
 // are equal.
 template <int KIND, bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const int* __restrict__ order_of,
-                                            const V3& o, const V3& d, double dd, double side_scale, Sweep& s,
+                                            const V3& o, const V3& d, double dd, double side_scale, double shadow_margin, Sweep& s,
                                             ContainerSlots& cs, SweepCounters& ctr) {
     const double* m = rec.m;
     const int tid = (int)threadIdx.x;
@@ -348,12 +356,21 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
         // disc < 0 in the reference's arithmetic: nothing below would change any state.
         // (distance^2 - r^2) * |d|^2 > (oc.d)^2, evaluated with fused operations: the margin
         // folded into br2 and kBoundShrink is thousands of times their rounding error.
-        const V3 oc = {rec.bc[0] - o.x, rec.bc[1] - o.y, rec.bc[2] - o.z};
-        const double ocd = fma(oc.z, d.z, fma(oc.y, d.y, oc.x * d.x));
-        const double oc2 = fma(oc.z, oc.z, fma(oc.y, oc.y, oc.x * oc.x));
-        const double apart = fma(oc2, kBoundShrink, -rec.br2) * dd;
-        if (STATS && apart > ocd * ocd) ++ctr.sphere_skips;
-        if (!(apart > ocd * ocd)) {
+        bool clear;
+        if (SHADOW) {
+            // a shadow ray ends at the light: the same test from there, with the sphere's part of
+            // it evaluated at upload (sphere_from_light, rtc_api.hip)
+            const double lcd = fma(rec.lc[2], d.z, fma(rec.lc[1], d.y, rec.lc[0] * d.x));
+            clear = rec.lk - shadow_margin > lcd * lcd;
+        } else {
+            const V3 oc = {rec.bc[0] - o.x, rec.bc[1] - o.y, rec.bc[2] - o.z};
+            const double ocd = fma(oc.z, d.z, fma(oc.y, d.y, oc.x * d.x));
+            const double oc2 = fma(oc.z, oc.z, fma(oc.y, oc.y, oc.x * oc.x));
+            const double apart = fma(oc2, kBoundShrink, -rec.br2) * dd;
+            clear = apart > ocd * ocd;
+        }
+        if (STATS && clear) ++ctr.sphere_skips;
+        if (!clear) {
         // Ray.transform (ray.zig:31-36), Sphere.localIntersect (shape.zig:23-45)
         V3 lo, ld;
         if (KIND == kSphereAxis) {
@@ -482,17 +499,17 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
 // arithmetic.  The two record buffers alternate, so no register copies are needed.
 template <int KIND, bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, const int* __restrict__ order_of, int begin,
-                                            int end, const V3& o, const V3& d, double dd, double side_scale, Sweep& s,
+                                            int end, const V3& o, const V3& d, double dd, double side_scale, double shadow_margin, Sweep& s,
                                             ContainerSlots& cs, SweepCounters& ctr) {
     if (begin >= end) return;
     ShapeRec A = load_rec(tab, begin);
     for (int i = begin; i < end; i += 2) {
         asm volatile("" ::"s"(A.order) : "memory");
         const ShapeRec B = load_rec(tab, i + 1);
-        sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, dd, side_scale, s, cs, ctr);
+        sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, dd, side_scale, shadow_margin, s, cs, ctr);
         asm volatile("" ::"s"(B.order) : "memory");
         A = load_rec(tab, i + 2);
-        if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, dd, side_scale, s, cs, ctr);
+        if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     }
 }
 
@@ -507,8 +524,9 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
 constexpr int kBvhStack = 64;  // the builder keeps the depth below 40 + ceil(log2(2^21 spheres)) = 61
 template <bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab, const int* __restrict__ order_of,
-                                                  const DevWorld& w, const V3& o, const V3& d, double dd, Sweep& s,
-                                                  ContainerSlots& cs, SweepCounters& ctr) {
+                                                  const DevWorld& w, const V3& o, const V3& d, double dd,
+                                                  double shadow_margin, Sweep& s, ContainerSlots& cs,
+                                                  SweepCounters& ctr) {
     const double inf = __builtin_huge_val();
     const double lim = w.bvh_origin_limit;
     // rays that start far outside the scene, or whose direction is degenerate, are not pruned
@@ -524,9 +542,9 @@ __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab
             const ShapeRec rec = load_rec(tab, pos);
             // the table keeps the spheres with a diagonal inverse first: they need six of the twelve entries
             if (pos < w.group[1])
-                sweep_shape<kSphereAxis, SHADOW, STATS>(rec, pos, order_of, o, d, dd, 0.0, s, cs, ctr);
+                sweep_shape<kSphereAxis, SHADOW, STATS>(rec, pos, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
             else
-                sweep_shape<kSphereGeneral, SHADOW, STATS>(rec, pos, order_of, o, d, dd, 0.0, s, cs, ctr);
+                sweep_shape<kSphereGeneral, SHADOW, STATS>(rec, pos, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
             if (SHADOW && s.idx >= 0) break;  // calc.isShadowed only asks whether anything is in the way
         } else {
             const BvhNode* __restrict__ n = w.bvh + cur;
@@ -585,19 +603,21 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     const double dd = fma(d.z, d.z, fma(d.y, d.y, d.x * d.x));  // for the bounding-sphere tests
     // for the same-side test of the planes: 1 + |o|_1 + |light|_1 bounds every magnitude in it
     const double side_scale = SHADOW ? ((fabs(o.x) + fabs(o.y)) + fabs(o.z)) + w.light_reach : 0.0;
+    // the per-ray term of the spheres' test from the light: 2^-25 dist^2 (s.t is the distance on entry)
+    const double shadow_margin = SHADOW ? 0x1p-25 * s.t * s.t : 0.0;
     s.idx = -1;
     if (!SHADOW) {
         s.t = 0.0;
         cs.i[0][tid] = -1;
         cs.i[1][tid] = -1;
     }
-    sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, dd, side_scale, s, cs, ctr);
-    sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, dd, side_scale, s, cs, ctr);
+    sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
+    sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     if (ACCEL) {
-        if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, s, cs, ctr);
+        if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, shadow_margin, s, cs, ctr);
     } else {
-        sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, side_scale, s, cs, ctr);
-        sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, side_scale, s, cs, ctr);
+        sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
+        sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     }
     if (!SHADOW) {
         s.top1 = cs.i[0][tid];

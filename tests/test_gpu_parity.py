@@ -20,7 +20,8 @@ from golden_io import GOLDEN_DIR, NAMES, Fixture
 from raytracer_challenge_amd import (Camera, Canvas, Color, Mat4, Material, Pattern, PointLight, Shape, World,
                                      byte_color_values, canvas_to_ppm, descs as D, init_glass_sphere, init_point,
                                      init_vector, native, scenes, tiles, view_transform)
-from worlds import grazing_world_and_rays, nested_glass_world, random_world, tie_world
+from worlds import (grazing_world_and_rays, nested_glass_world, random_world, shadow_grazing_world_and_rays,
+                    tie_world)
 
 pytestmark = pytest.mark.gpu
 
@@ -315,6 +316,20 @@ def test_grazing_rays_on_small_large_far_and_stretched_spheres(seed):
     assert_identical(got, want, f"grazing rays, seed {seed}")
     hit = np.any(want != 0, axis=1)
     assert 0.2 < hit.mean() < 0.995  # the set straddles hit and miss
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_shadow_rays_that_graze_spheres(seed):
+    """calc.isShadowed (calc.zig:777-790) for floor points whose line to the light touches a sphere
+    within 1e-15 ... 1e-6 of its angular size: list walk and hierarchy against the oracle."""
+    w, rays = shadow_grazing_world_and_rays(seed)
+    cpu = O.color_at(w, rays, 2, O.STREAMING)
+    shadowed = np.count_nonzero(cpu[:, 0] < 0.1)  # ambient only
+    assert 0.2 * len(rays) < shadowed < 0.8 * len(rays)  # the aim is good enough to split the points
+    with scene_of(w) as sc:
+        assert_identical(sc.color_at(rays, 2), cpu, "shadow grazing, list walk")
+        sc.set_acceleration(D.RTC_ACCEL_BVH)
+        assert_identical(sc.color_at(rays, 2), cpu, "shadow grazing, hierarchy")
 
 
 def test_worlds_beyond_the_lds_table_size_and_one_kind_worlds():

@@ -151,3 +151,71 @@ def grazing_world_and_rays(seed, n_rays=6000):
         rays[k, :3] = o
         rays[k, 3:] = d
     return w, rays
+
+
+def shadow_grazing_world_and_rays(seed, n_rays=2500):
+    """Shadow rays that graze spheres: rays aimed at floor points q chosen so that the line from q
+    to the light touches a sphere (tangency found by bisection on the discriminant in double
+    precision), then turned away from or into the sphere by 0, +-1e-15 ... +-1e-6 of the sphere's
+    angular size.  Whether such a point is in shadow is decided in the last bits of the
+    reference's discriminant; the device's test from the light must never get ahead of it.
+    Tiny, large, stretched and sheared spheres, near and far from the light."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    w = World()
+    light = np.array([u(-3, 3), u(20, 30), u(-3, 3)])
+    w.light = PointLight(init_point(*light), Color(1, 1, 1))
+    floor_y = -3.0
+    w.objects.append(Shape("plane", Mat4.identity().translate(0, floor_y, 0),
+                           Material(color=Color(0.9, 0.9, 0.9), specular=0.0, reflective=0.2 if seed % 2 else 0.0)))
+    mats = []
+    for kind in range(9):
+        size = 10.0 ** u(-3, 0.7) if kind % 3 else u(0.5, 2)
+        m = Mat4.identity()
+        if kind < 3:
+            m = m.scale(size, size, size)
+        elif kind < 6:
+            m = m.scale(size * u(0.2, 1), size * u(0.2, 1), size * u(0.2, 1))
+        else:
+            m = (m.scale(size * u(0.3, 1), size * u(0.3, 1), size * u(0.3, 1)).rotate_x(u(0, 3)).rotate_z(u(0, 3))
+                 .shear(u(-0.3, 0.3), 0, 0, 0, u(-0.3, 0.3), 0))
+        c = np.array([u(-12, 12), u(0, 15) if kind % 2 else u(18, 19.9), u(-12, 12)])
+        m = m.translate(float(c[0]), float(c[1]), float(c[2]))
+        w.objects.append(Shape("sphere", m, Material(color=Color(u(0.2, 1), u(0.2, 1), u(0.2, 1)), ambient=0.3)))
+        a = np.array(m.mat, dtype=np.float64).reshape(4, 4)
+        mats.append((np.linalg.inv(a), c))
+
+    def disc(inv, direction):
+        lo = inv[:3, :3] @ light + inv[:3, 3]
+        ld = inv[:3, :3] @ direction
+        b = 2 * ld.dot(lo)
+        return b * b - 4 * ld.dot(ld) * (lo.dot(lo) - 1)
+
+    rays = np.empty((n_rays, 6))
+    k = 0
+    while k < n_rays:
+        inv, c = mats[int(rng.integers(0, len(mats)))]
+        axis0 = c - light
+        axis0 /= np.linalg.norm(axis0)
+        side = np.cross(axis0, rng.normal(size=3))
+        side /= np.linalg.norm(side)
+        turned = lambda alpha: np.cos(alpha) * axis0 + np.sin(alpha) * side
+        lo_a, hi_a = 0.0, 1.0
+        if disc(inv, turned(lo_a)) <= 0 or disc(inv, turned(hi_a)) >= 0:
+            continue
+        for _ in range(64):
+            mid = 0.5 * (lo_a + hi_a)
+            if disc(inv, turned(mid)) > 0:
+                lo_a = mid
+            else:
+                hi_a = mid
+        eps = (0.0, 1e-15, -1e-15, 1e-13, -1e-13, 1e-11, -1e-11, 1e-9, -1e-9, 1e-6, -1e-6)[int(rng.integers(0, 11))]
+        direction = turned(lo_a * (1.0 + eps))
+        if direction[1] > -1e-3:
+            continue
+        q = light + direction * ((floor_y - light[1]) / direction[1])
+        eye = np.array([u(-5, 5), u(1, 12), u(-40, -25)])
+        rays[k, :3] = eye
+        rays[k, 3:] = (q - eye) / np.linalg.norm(q - eye)
+        k += 1
+    return w, rays
