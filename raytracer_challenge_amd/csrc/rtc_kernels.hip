@@ -1164,31 +1164,35 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 bool has_refract = false;
                 V3 refr_dir = {0, 0, 0};
                 const double cos_i = dot3(eyev, normalv);
-                if (remaining > 0 && !(fabs(m_transparency) <= kF64Eps)) {
-                    const double n_ratio = n1 / n2;
-                    const double sin2_t = n_ratio * n_ratio * (1 - cos_i * cos_i);
-                    if (!(sin2_t > 1.0)) {
-                        const double cos_t = sqrt(1.0 - sin2_t);
-                        const double kn = n_ratio * cos_i - cos_t;
-                        refr_dir = {kn * normalv.x - n_ratio * eyev.x, kn * normalv.y - n_ratio * eyev.y,
-                                    kn * normalv.z - n_ratio * eyev.z};
-                        has_refract = true;
-                    }
+                // calc.refractedColor (calc.zig:836-846) and, leaving a denser medium, calc.schlick
+                // (calc.zig:1010-1018) form the same ratio, sin2_t and cos_t from the same values:
+                // evaluated once for both
+                const bool refract_wanted = remaining > 0 && !(fabs(m_transparency) <= kF64Eps);
+                const bool schlick_wanted = m_reflective > 0.0 && m_transparency > 0.0;
+                double n_ratio = 0.0, sin2_t = 0.0, cos_t = 0.0;
+                if (refract_wanted || (schlick_wanted && n1 > n2)) {
+                    n_ratio = n1 / n2;
+                    sin2_t = n_ratio * n_ratio * (1 - cos_i * cos_i);
+                    if (!(sin2_t > 1.0)) cos_t = sqrt(1.0 - sin2_t);
+                }
+                if (refract_wanted && !(sin2_t > 1.0)) {
+                    const double kn = n_ratio * cos_i - cos_t;
+                    refr_dir = {kn * normalv.x - n_ratio * eyev.x, kn * normalv.y - n_ratio * eyev.y,
+                                kn * normalv.z - n_ratio * eyev.z};
+                    has_refract = true;
                 }
                 int flags = has_refract ? kHasRefract : 0;
                 double R = 0.0;
-                if (m_reflective > 0.0 && m_transparency > 0.0) {
+                if (schlick_wanted) {
                     // calc.schlick (calc.zig:1004-1026)
                     flags |= kSchlick;
                     double cosv = cos_i;
                     bool tir = false;
                     if (n1 > n2) {
-                        const double nn = n1 / n2;
-                        const double sin2_t = nn * nn * (1.0 - cosv * cosv);
                         if (sin2_t > 1.0)
                             tir = true;
                         else
-                            cosv = sqrt(1.0 - sin2_t);
+                            cosv = cos_t;
                     }
                     if (tir) {
                         R = 1.0;
