@@ -1094,7 +1094,13 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     // a plane's normal does not depend on the point: evaluated at upload
                     normalv = {sh.plane_normal[0], sh.plane_normal[1], sh.plane_normal[2]};
                 }
-                if (dot3(normalv, eyev) < 0) normalv = {-normalv.x, -normalv.y, -normalv.z};
+                // normalv.dot(eyev) decides the flip (calc.zig:256-259); eyev.dot(normalv) of the
+                // refraction terms and ray.direction.dot(normalv) of reflect() are the same three
+                // products and two sums up to signs, which rounding does not see
+                const double n_dot_e = dot3(normalv, eyev);
+                const bool inside = n_dot_e < 0;
+                if (inside) normalv = {-normalv.x, -normalv.y, -normalv.z};
+                const double cos_i = inside ? -n_dot_e : n_dot_e;
                 const V3 offs = {kSurfaceEps * normalv.x, kSurfaceEps * normalv.y, kSurfaceEps * normalv.z};
                 const V3 over_point = {point.x + offs.x, point.y + offs.y, point.z + offs.z};
 
@@ -1125,7 +1131,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 const double n1 = ri_top1;
                 const double n2 = exit_open ? ri_rest : m_ri;
                 // the rest of calc.prepareComputations (deferred past the shadow sweep: fewer live registers)
-                const double two_dp = 2.0 * dot3(rd, normalv);  // Vec4.reflect, vector.zig:114-117
+                const double two_dp = 2.0 * -cos_i;  // Vec4.reflect, vector.zig:114-117: 2 * direction.dot(normalv)
                 const V3 reflectv = {rd.x - two_dp * normalv.x, rd.y - two_dp * normalv.y, rd.z - two_dp * normalv.z};
                 const V3 under_point = {point.x - offs.x, point.y - offs.y, point.z - offs.z};
 
@@ -1163,7 +1169,6 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 const bool has_reflect = remaining > 0 && !(fabs(m_reflective) <= kF64Eps);
                 bool has_refract = false;
                 V3 refr_dir = {0, 0, 0};
-                const double cos_i = dot3(eyev, normalv);
                 // calc.refractedColor (calc.zig:836-846) and, leaving a denser medium, calc.schlick
                 // (calc.zig:1010-1018) form the same ratio, sin2_t and cos_t from the same values:
                 // evaluated once for both
