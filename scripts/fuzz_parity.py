@@ -3,7 +3,7 @@ glass and mirrors, patterns), random canvas sizes, depths 0-7, list walk and hie
 canvas and interleaved partitions, each compared value for value with the CPU oracle
 (streaming integrator; every 10th world also with the literal one).  Runs until the time budget
 is spent and prints the seeds that differ.
-usage: fuzz_parity.py [seconds [first_seed]]"""
+usage: fuzz_parity.py [seconds [first_seed [most spheres per world, default 40]]]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
@@ -14,12 +14,13 @@ from worlds import random_world
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+most_spheres = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 t_end = time.time() + budget
 done = bad = rays = 0
 t_print = time.time()
 while time.time() < t_end:
     rng = np.random.default_rng(seed ^ 0x5EED)
-    n_s, n_p = int(rng.integers(0, 41)), int(rng.integers(0, 5))
+    n_s, n_p = int(rng.integers(0, most_spheres + 1)), int(rng.integers(0, 5))
     w, c = random_world(seed, n_spheres=n_s, n_planes=n_p, glass=bool(rng.integers(0, 4)))
     cam = Camera(int(rng.integers(1, 97)), int(rng.integers(1, 97)), c.field_of_view)
     cam.transform = c.transform
