@@ -16,7 +16,10 @@
 // that is unwound in the reference's post-order, so the colour sums associate exactly as
 // in calc.zig:464-469.  Every loop iteration each live lane processes one tree node: a
 // radiance sweep over all shapes, then (on a hit) a shadow sweep and the shading.  The
-// sweep tests every shape, as calc.intersectWorld does; the shapes are visited group by
+// sweep visits every shape, as calc.intersectWorld does (a pair is cut short only where a
+// conservative test with a stated margin proves that the reference's own arithmetic finds
+// nothing that matters: the bounding-sphere tests, the light-side test of the shadow sweep,
+// the root filters); the shapes are visited group by
 // group (four kinds, one specialised loop each) rather than in list order, and equal t are
 // resolved by list index, which selects what the reference's stable sort selects.  It is the
 // same work for every lane whatever ray it holds, so a wavefront does not diverge over the
