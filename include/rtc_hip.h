@@ -170,7 +170,17 @@ int rtc_scene_group_counts(const RtcScene* scene, uint64_t out_counts[4]);
 /* Camera.render (camera.zig:74-89): fill out_rgb (host memory, hsize*vsize*3 doubles,
  * pixel (x,y) at index (y*hsize + x)*3 as canvas.zig:25, channels red,green,blue as
  * color.zig:7-9) with calc.worldColorAt(world, rayForPixel(x,y), depth).  The
- * reference hard-codes depth 5 (camera.zig:83).  stats may be NULL. */
+ * reference hard-codes depth 5 (camera.zig:83).  depth is the reference's i32 `remaining`
+ * (calc.zig:641): a value <= 0 spawns no secondary rays (calc.zig:829,946), so a negative depth
+ * renders like depth 0; the largest supported depth is 16 (RTC_ERR_TOO_LARGE beyond).  This holds
+ * for every entry point that takes a depth.  stats may be NULL.
+ *
+ * Concurrency (all render entry points): the launches of one scene share the scene's control
+ * block, tile plan, timing events and staging buffers.  At most one launch per scene may be in
+ * flight at a time (later launches on the same stream are ordered by the stream; launches on
+ * different streams or threads must be serialised by the caller, or use one scene handle each),
+ * and the scene's device (the one current in rtc_scene_create) must be the current device of the
+ * calling thread, else RTC_ERR_INVALID_ARGUMENT. */
 int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, double* out_rgb,
                RtcStats* stats);
 

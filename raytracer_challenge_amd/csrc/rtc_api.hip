@@ -277,9 +277,9 @@ int check_camera(const RtcCameraDesc* c) {
 }
 
 // Fill stats from the device counters (after the stream has been synchronised).
-int read_stats(RtcScene* s, RtcStats* out, uint64_t pixels, float ms) {
+int read_stats(RtcScene* s, const uint64_t* d_stats, RtcStats* out, uint64_t pixels, float ms) {
     uint64_t h[7];
-    HIP_TRY(hipMemcpy(h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     out->radiance_rays = h[0];
     out->shadow_rays = h[1];
     out->sphere_tests = (h[0] + h[1]) * s->n_spheres;
@@ -377,7 +377,12 @@ int32_t build_bvh(std::vector<RtcScene::SphereBox>& items, size_t begin, size_t 
         }
         return ~items[begin].pos;
     }
-    auto centre = [](const RtcScene::SphereBox& x, int a) { return 0.5 * x.lo[a] + 0.5 * x.hi[a]; };
+    // an unbounded sphere has an infinite box; its centre is taken as 0 so that the keys below
+    // stay totally ordered (-inf + inf would be NaN)
+    auto centre = [](const RtcScene::SphereBox& x, int a) {
+        const double c = 0.5 * x.lo[a] + 0.5 * x.hi[a];
+        return c == c ? c : 0.0;
+    };
     double cmin[3] = {1e300, 1e300, 1e300}, cmax[3] = {-1e300, -1e300, -1e300};
     bool finite = true;
     for (size_t k = begin; k < end; ++k)
@@ -509,17 +514,12 @@ double largest_stretch(const double* m) {
 // tiles together is faster than one that scatters them, and queueing the costly rows first is
 // worth about 7 % of the frame time over a top-to-bottom scan.
 // This only orders the work: every pixel is computed by the same arithmetic whatever its
-// place in the queue.  Sets job->tile_order (nullptr = natural order).  The plan is cached
-// per camera and partition.
-int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uint64_t local_tiles,
-                    hipStream_t stream) {
-    job->tile_order = nullptr;
+// place in the queue.  This function is the host arithmetic (queue slot -> local tile index);
+// `order` comes back empty when the natural order is kept.
+int compute_tile_order(const RtcScene* s, const RtcCameraDesc* cam, const rtc::DevJob* job, uint64_t local_tiles,
+                       std::vector<uint32_t>& order) {
+    order.clear();
     if (local_tiles < 2 || s->costly_everywhere || s->costly.empty()) return RTC_OK;
-    if (s->plan_valid && s->plan_rank == job->tile_rank && s->plan_ranks == job->tile_ranks &&
-        std::memcmp(&s->plan_camera, cam, sizeof *cam) == 0) {
-        job->tile_order = s->plan_identity ? nullptr : s->d_tile_order;
-        return RTC_OK;
-    }
     const uint32_t tiles_x = job->tiles_x, ranks = job->tile_ranks, rank = job->tile_rank;
     const uint32_t tiles_y = job->tiles_total / tiles_x;
     std::vector<uint64_t> row_score(tiles_y, 0);
@@ -554,11 +554,6 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
         boxes.push_back({tx0, tx1, ty0, ty1});
         any = true;
     }
-    s->plan_camera = *cam;
-    s->plan_rank = rank;
-    s->plan_ranks = ranks;
-    s->plan_valid = true;
-    s->plan_identity = !any;
     if (!any) return RTC_OK;
     // rank of every row of tiles in the queue
     std::vector<uint32_t> dist_to_costly(tiles_y, tiles_y);
@@ -587,7 +582,7 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
     std::vector<uint64_t> start(tiles_y + 1, 0);
     for (uint64_t k = 0; k < local_tiles; ++k) ++start[rank_of_row[(k * ranks + rank) / tiles_x] + 1];
     for (uint32_t i = 0; i < tiles_y; ++i) start[i + 1] += start[i];
-    std::vector<uint32_t> order(local_tiles);
+    order.resize(local_tiles);
     for (uint64_t k = 0; k < local_tiles; ++k) order[start[rank_of_row[(k * ranks + rank) / tiles_x]]++] = (uint32_t)k;
     // A block of 64 such pixels keeps its wave for some 60 node iterations, about 0.4 ms: on a
     // share of the frame that the whole GPU finishes in little more than that, every one of them
@@ -607,22 +602,42 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
         };
         std::stable_partition(order.begin(), order.end(), marked);
     }
+    return RTC_OK;
+}
+
+// The plan in the scene's own buffer (grown with hipMalloc when needed), cached per camera and partition.
+int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uint64_t local_tiles,
+                    hipStream_t stream) {
+    job->tile_order = nullptr;
+    if (local_tiles < 2 || s->costly_everywhere || s->costly.empty()) return RTC_OK;
+    if (s->plan_valid && s->plan_rank == job->tile_rank && s->plan_ranks == job->tile_ranks &&
+        std::memcmp(&s->plan_camera, cam, sizeof *cam) == 0) {
+        job->tile_order = s->plan_identity ? nullptr : s->d_tile_order;
+        return RTC_OK;
+    }
+    std::vector<uint32_t> order;
+    if (int rc = compute_tile_order(s, cam, job, local_tiles, order)) return rc;
+    // the cache describes a plan only once that plan is on the device (or needs no upload)
+    s->plan_valid = false;
+    s->plan_camera = *cam;
+    s->plan_rank = job->tile_rank;
+    s->plan_ranks = job->tile_ranks;
+    s->plan_identity = order.empty();
+    if (order.empty()) {
+        s->plan_valid = true;
+        return RTC_OK;
+    }
     // an earlier launch on this stream may still be reading the previous plan
     HIP_TRY(hipStreamSynchronize(stream));
     if (s->tile_order_capacity < local_tiles) {
-        s->plan_valid = false;
         if (s->d_tile_order) (void)hipFree(s->d_tile_order);
         s->d_tile_order = nullptr;
         s->tile_order_capacity = 0;
         HIP_TRY(hipMalloc((void**)&s->d_tile_order, local_tiles * sizeof(uint32_t)));
         s->tile_order_capacity = local_tiles;
-        s->plan_valid = true;
     }
-    hipError_t e = hipMemcpy(s->d_tile_order, order.data(), local_tiles * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        s->plan_valid = false;
-        return fail_hip("hipMemcpy(tile order)", e);
-    }
+    HIP_TRY(hipMemcpy(s->d_tile_order, order.data(), local_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+    s->plan_valid = true;
     job->tile_order = s->d_tile_order;
     return RTC_OK;
 }
@@ -727,14 +742,30 @@ int copy_canvas_to_host(RtcScene* s, const void* d_src, void* dst, size_t bytes)
 }
 
 // Common launch path of rtc_render_device / rtc_render / rtc_color_at.
-int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, uint64_t pixels) {
+// `control` is the launch's control block: the scene's own (nullptr) or the caller's.
+int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, uint64_t pixels,
+            uint32_t* control = nullptr) {
     if (job.depth > rtc::kMaxDepthLarge) {
         char buf[96];
         std::snprintf(buf, sizeof buf, "depth %d exceeds the supported maximum %d", job.depth, rtc::kMaxDepthLarge);
         return fail(RTC_ERR_TOO_LARGE, buf);
     }
-    job.counter = s->d_counter;
-    job.stats = stats ? s->d_stats : nullptr;
+    // calc.zig:829,946 take an i32 `remaining` and spawn no children for remaining <= 0: a negative
+    // depth renders like depth 0 (and must not reach the kernel, whose task word holds it unsigned)
+    if (job.depth < 0) job.depth = 0;
+    // every launch of a scene shares its control block, tile plan and events: the scene's device
+    // must be the current one (the caller's stream and output buffer live there too)
+    int current_device = -1;
+    HIP_TRY(hipGetDevice(&current_device));
+    if (current_device != s->device) {
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "scene was created on device %d but device %d is current", s->device, current_device);
+        return fail(RTC_ERR_INVALID_ARGUMENT, buf);
+    }
+    if (!control) control = s->d_counter;
+    uint64_t* control_stats = (uint64_t*)((char*)control + rtc::kStatsOffsetBytes);
+    job.counter = control;
+    job.stats = stats ? control_stats : nullptr;
     if (job.total == 0) {
         if (stats) {
             std::memset(stats, 0, sizeof *stats);
@@ -742,7 +773,7 @@ int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, 
         return RTC_OK;
     }
     // zero the queue head and the stats words
-    HIP_TRY(hipMemsetAsync(s->d_counter, 0, rtc::kProbeOffsetBytes, stream));
+    HIP_TRY(hipMemsetAsync(control, 0, rtc::kProbeOffsetBytes, stream));
     if (stats) HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(rtc::launch_render(dev_world(s), job, stats != nullptr, stream));
     if (stats) {
@@ -750,7 +781,7 @@ int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, 
         HIP_TRY(hipEventSynchronize(s->ev_stop));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
-        return read_stats(s, stats, pixels, ms);
+        return read_stats(s, control_stats, stats, pixels, ms);
     }
     return RTC_OK;
 }

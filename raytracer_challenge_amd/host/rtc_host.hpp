@@ -259,6 +259,8 @@ struct Camera {
 
     // Camera.render (camera.zig:74-89) through the HIP library; the reference's depth is 5.
     Canvas render(const World& world, int depth = 5, RtcStats* stats = nullptr) const {
+        // an empty canvas has no first pixel to point at: the library refuses it by name
+        if (hsize == 0 || vsize == 0) throw RenderError(RTC_ERR_INVALID_ARGUMENT, "camera hsize/vsize must be non-zero");
         Canvas canvas(hsize, vsize);
         through_library(world, [&](RtcScene* scene, const RtcCameraDesc& cam) {
             return rtc_render(scene, &cam, depth, &canvas.pixels[0].red, stats);
@@ -269,6 +271,7 @@ struct Camera {
     // Camera.render and the byteColorValue half of canvasToPPM (ppm.zig:6-9) in one call: the
     // colours are quantised on the device and bytesToPPM only formats.
     ByteCanvas renderBytes(const World& world, int depth = 5, RtcStats* stats = nullptr) const {
+        if (hsize == 0 || vsize == 0) throw RenderError(RTC_ERR_INVALID_ARGUMENT, "camera hsize/vsize must be non-zero");
         ByteCanvas canvas(hsize, vsize);
         through_library(world, [&](RtcScene* scene, const RtcCameraDesc& cam) {
             return rtc_render_u8(scene, &cam, depth, canvas.rgb.data(), stats);

@@ -369,6 +369,59 @@ def test_depth_beyond_the_supported_maximum_is_refused():
     assert e.value.code == D.RTC_ERR_TOO_LARGE
 
 
+def test_negative_depth_renders_like_depth_zero():
+    """calc.zig:829,946: `remaining` is an i32 and a value <= 0 spawns no children."""
+    w, c = scenes.draw_world_scene(96, 48)
+    want = O.render(w, c, 0, O.STREAMING)
+    for depth in (-1, -5, -(2 ** 31)):
+        assert_identical(O.render(w, c, depth, O.STREAMING), want, f"oracle depth {depth}")
+        assert_identical(c.render(w, depth).pixels, want, f"depth {depth}")
+    rays = np.array([[0, 0, -5, 0, 0, 1.0], [0, 1, -5, 0, 0, 1.0]])
+    with scene_of(w) as sc:
+        assert_identical(sc.color_at(rays, -1), O.color_at(w, rays, 0, O.LITERAL), "color_at depth -1")
+        assert np.array_equal(sc.render_u8(c.desc(), -3), O.quantize_u8(want).reshape(want.shape))
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 7, 11, 40])
+def test_partitions_of_a_ragged_canvas(ranks):
+    """rtc_render_device + rtc_deinterleave(_u8)_device with rank counts that do not divide the tile
+    count, and with more ranks than tiles (the surplus ranks have an empty share), on a canvas whose
+    edge tiles are cut: the assembled canvas equals the 1-rank canvas and the oracle's."""
+    import torch
+
+    hs, vs = 200, 43  # 4 x 6 = 24 tiles, the last column 8 pixels wide, the last row 3 pixels high
+    w, c = scenes.draw_world_scene(hs, vs)
+    cd = c.desc()
+    dev = torch.device("cuda", 0)
+    with scene_of(w) as sc:
+        full = torch.empty(hs * vs * 3, dtype=torch.float64, device=dev)
+        sc.render_device(cd, 5, full.data_ptr())
+        n0 = native.tile_buffer_doubles(cd, 0, ranks)
+        gathered = torch.full((ranks, max(n0, 1)), -3.0, dtype=torch.float64, device=dev)
+        total_rays = 0
+        for r in range(ranks):
+            nr = native.tile_buffer_doubles(cd, r, ranks)
+            assert nr == tiles.local_tile_count(hs, vs, r, ranks) * D.RTC_TILE_W * D.RTC_TILE_H * 3
+            st = D.RtcStats()
+            sc.render_device(cd, 5, gathered[r].data_ptr(), r, ranks, None, st)
+            assert (st.radiance_rays == 0) == (nr == 0)
+            total_rays += st.radiance_rays
+        canvas = torch.full((hs * vs * 3,), -1.0, dtype=torch.float64, device=dev)
+        native.deinterleave_device(cd, ranks, gathered.shape[1], gathered.data_ptr(), canvas.data_ptr())
+        gq = torch.empty(gathered.shape, dtype=torch.uint8, device=dev)
+        native.quantize_u8_device(gathered.data_ptr(), gathered.numel(), gq.data_ptr())
+        q = torch.full((hs * vs * 3,), 77, dtype=torch.uint8, device=dev)
+        native.deinterleave_u8_device(cd, ranks, gathered.shape[1], gq.data_ptr(), q.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(canvas, full)
+        st1 = D.RtcStats()
+        sc.render_device(cd, 5, full.data_ptr(), 0, 1, None, st1)
+        assert total_rays == st1.radiance_rays
+    host = full.cpu().numpy().reshape(vs, hs, 3)
+    assert_identical(host, O.render(w, c, 5, O.STREAMING), "ragged canvas")
+    assert np.array_equal(q.cpu().numpy().reshape(vs, hs, 3), byte_color_values(host))
+
+
 @pytest.mark.parametrize("size", [(1, 1), (70, 9), (63, 7), (129, 17)])
 def test_ragged_canvas_sizes(size):
     w, c = scenes.draw_world_scene(*size)
