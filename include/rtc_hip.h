@@ -199,6 +199,23 @@ int rtc_render_device(RtcScene* scene, const RtcCameraDesc* camera, int32_t dept
                       uint32_t tile_rank, uint32_t tile_ranks, void* d_out_rgb, void* hip_stream,
                       RtcStats* stats);
 
+/* rtc_render_device for callers that cannot allocate device memory.  This entry point has no
+ * counterpart in the reference; it exists for callers that must not call hipMalloc: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid allocation.  It renders exactly
+ * what rtc_render_device renders (same arguments, same output layout, same values) but keeps the
+ * launch's scratch data — the control block with the work-queue heads and statistics counters,
+ * and the queue plan of one uint32 per local tile — in a fixed array in the library's device
+ * image instead of buffers of the scene, and calls no hipMalloc / hipFree or other allocating
+ * routine.  Limit: at most RTC_NOALLOC_MAX_TILES local tiles (tiles of this rank's share:
+ * 7680x4320 on one rank is 64 800), RTC_ERR_TOO_LARGE beyond.  The array (about 1 MiB) exists
+ * once per GPU and is shared by every call on that GPU, whatever the scene: calls that overlap
+ * on one GPU (two streams, two threads) race on it and must be serialised by the caller.  The
+ * scene itself must have been created before (rtc_scene_create allocates). */
+#define RTC_NOALLOC_MAX_TILES 262144
+int rtc_render_device_noalloc(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth,
+                              uint32_t tile_rank, uint32_t tile_ranks, void* d_out_rgb,
+                              void* hip_stream, RtcStats* stats);
+
 /* Number of doubles rtc_render_device writes into for (camera, tile_rank, tile_ranks). */
 int rtc_tile_buffer_doubles(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks,
                             uint64_t* out_doubles);

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <atomic>
 #include <string>
@@ -815,6 +816,49 @@ int fill_camera_job(const RtcCameraDesc* camera, int32_t depth, uint32_t tile_ra
     return RTC_OK;
 }
 
+// ---- the entry point that allocates nothing (rtc_render_device_noalloc) -------------------
+// What a launch needs beyond its inputs and outputs is the control block (work-queue heads and
+// statistics counters) and the queue plan (one uint32 per local tile).  rtc_render_device keeps
+// both in buffers the scene allocated; this variant keeps them in a file-scope device array, so
+// that a caller that cannot call hipMalloc (graph capture, a serving loop with a fixed memory
+// budget) can still launch.  Every GPU the library runs on holds its own copy of the array, at
+// its own address, until the process ends.
+constexpr uint32_t kNoAllocMaxTiles = RTC_NOALLOC_MAX_TILES;
+constexpr size_t kScratchControlBytes = 4096;  // >= kProbeOffsetBytes, keeps the plan 256-byte aligned
+static_assert(rtc::kProbeOffsetBytes <= (int)kScratchControlBytes, "control block fits its slot");
+constexpr size_t kScratchBytes = kScratchControlBytes + (size_t)kNoAllocMaxTiles * sizeof(uint32_t);
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+// Host code never uses the array's name as an address (it is a host-side stand-in): the device
+// address is asked for once per device, with that device current, and kept here.
+constexpr int kMaxDevices = 64;
+struct ScratchSlot {
+    unsigned char* ptr = nullptr;  // device address of this device's copy of `scratch`
+    // the plan the copy holds: scene, camera and partition it was computed for
+    bool plan_valid = false, plan_identity = true;
+    const RtcScene* plan_scene = nullptr;
+    RtcCameraDesc plan_camera{};
+    uint32_t plan_rank = 0, plan_ranks = 0;
+};
+ScratchSlot g_scratch_slots[kMaxDevices];
+std::mutex g_scratch_mutex;
+
+int scratch_of_current_device(ScratchSlot** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(RTC_ERR_TOO_LARGE, "device index beyond the scratch table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    ScratchSlot& slot = g_scratch_slots[dev];
+    if (!slot.ptr) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RTC_ERR_DEVICE, "hipGetSymbolAddress(scratch) returned NULL");
+        slot.ptr = (unsigned char*)p;
+    }
+    *out = &slot;
+    return RTC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1020,6 +1064,12 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
 }
 
 int rtc_scene_destroy(RtcScene* scene) {
+    {
+        // a later scene may be allocated at the same address: forget the plans kept for this one
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        for (ScratchSlot& slot : g_scratch_slots)
+            if (slot.plan_scene == scene) slot.plan_valid = false;
+    }
     free_scene(scene);
     return RTC_OK;
 }
@@ -1091,6 +1141,57 @@ int rtc_render_device(RtcScene* scene, const RtcCameraDesc* camera, int32_t dept
         return rc;
     const uint64_t pixels = tile_ranks == 1 ? camera->hsize * camera->vsize : local_pixels;
     return run_job(scene, job, (hipStream_t)hip_stream, stats, pixels);
+}
+
+int rtc_render_device_noalloc(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, uint32_t tile_rank,
+                              uint32_t tile_ranks, void* d_out_rgb, void* hip_stream, RtcStats* stats) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!valid_stream_and_ptr(d_out_rgb)) return fail(RTC_ERR_INVALID_ARGUMENT, "d_out_rgb is NULL");
+#ifdef RTC_PROBE
+    return fail(RTC_ERR_INVALID_ARGUMENT, "the developer probe build writes beyond the control block");
+#endif
+    rtc::DevJob job{};
+    uint64_t local_pixels = 0;
+    if (int rc = fill_camera_job(camera, depth, tile_rank, tile_ranks, &job, &local_pixels)) return rc;
+    const uint64_t local_tiles = local_pixels / (RTC_TILE_W * RTC_TILE_H);
+    if (local_tiles > kNoAllocMaxTiles) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "rtc_render_device_noalloc: %llu local tiles exceed RTC_NOALLOC_MAX_TILES (%u)",
+                      (unsigned long long)local_tiles, kNoAllocMaxTiles);
+        return fail(RTC_ERR_TOO_LARGE, buf);
+    }
+    job.out = (double*)d_out_rgb;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    ScratchSlot* slot = nullptr;
+    if (int rc = scratch_of_current_device(&slot)) return rc;
+    uint32_t* control = (uint32_t*)slot->ptr;
+    uint32_t* d_plan = (uint32_t*)(slot->ptr + kScratchControlBytes);
+    // queue plan: same arithmetic as rtc_render_device, kept in the scratch array instead of a
+    // buffer of the scene; the array remembers which scene, camera and partition it serves
+    job.tile_order = nullptr;
+    if (!(local_tiles < 2 || scene->costly_everywhere || scene->costly.empty())) {
+        const bool cached = slot->plan_valid && slot->plan_scene == scene && slot->plan_rank == tile_rank &&
+                            slot->plan_ranks == tile_ranks && std::memcmp(&slot->plan_camera, camera, sizeof *camera) == 0;
+        if (!cached) {
+            std::vector<uint32_t> order;
+            if (int rc = compute_tile_order(scene, camera, &job, local_tiles, order)) return rc;
+            slot->plan_valid = false;
+            if (!order.empty()) {
+                // an earlier launch on this stream may still be reading the previous plan
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipMemcpy(d_plan, order.data(), local_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
+            slot->plan_scene = scene;
+            slot->plan_camera = *camera;
+            slot->plan_rank = tile_rank;
+            slot->plan_ranks = tile_ranks;
+            slot->plan_identity = order.empty();
+            slot->plan_valid = true;
+        }
+        job.tile_order = slot->plan_identity ? nullptr : d_plan;
+    }
+    const uint64_t pixels = tile_ranks == 1 ? camera->hsize * camera->vsize : local_pixels;
+    return run_job(scene, job, stream, stats, pixels, control);
 }
 
 int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, double* out_rgb, RtcStats* stats) {

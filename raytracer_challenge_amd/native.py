@@ -50,6 +50,7 @@ def lib():
     L.rtc_render.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, dp, C.POINTER(D.RtcStats)]
     L.rtc_render_u8.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, C.POINTER(C.c_uint8), C.POINTER(D.RtcStats)]
     L.rtc_render_device.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
+    L.rtc_render_device_noalloc.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
     L.rtc_tile_buffer_doubles.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, C.POINTER(u64)]
     L.rtc_deinterleave_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
     L.rtc_deinterleave_u8_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
@@ -76,6 +77,7 @@ EXPORTS = (
     "rtc_render",
     "rtc_render_u8",
     "rtc_render_device",
+    "rtc_render_device_noalloc",
     "rtc_tile_buffer_doubles",
     "rtc_deinterleave_device",
     "rtc_deinterleave_u8_device",
@@ -198,6 +200,15 @@ class Scene:
         sp = C.byref(stats) if stats is not None else None
         check(
             lib().rtc_render_device(
+                self._h, C.byref(camera_desc), int(depth), tile_rank, tile_ranks, C.c_void_p(d_out), stream, sp
+            )
+        )
+
+    def render_device_noalloc(self, camera_desc, depth, d_out, tile_rank=0, tile_ranks=1, stream=None, stats=None):
+        """rtc_render_device_noalloc: as render_device, scratch data in the library's fixed device array."""
+        sp = C.byref(stats) if stats is not None else None
+        check(
+            lib().rtc_render_device_noalloc(
                 self._h, C.byref(camera_desc), int(depth), tile_rank, tile_ranks, C.c_void_p(d_out), stream, sp
             )
         )
