@@ -951,6 +951,58 @@ inline void render(const Camera& cam, World& world, int depth, Mode mode, double
     }
 }
 
+// draw_sphere.zig:22-83 — the Ch. 6 "plumbing" program: one unit sphere of colour (1, 0.2, 1), a white
+// light at (-10, 10, -10), the eye at (0, 0, -5), a wall of size 7 at z = 10 sampled at pixel CORNERS
+// (world_x = -half + x * pixel_size, draw_sphere.zig:52,58), no shadows, lighting at the hit point itself.
+// The file is stale against the mounted revision (it imports sphere.zig and calls calc.intersectSphere,
+// calc.sphereNormalAt and a five-argument lighting, none of which exist any more); its loop is restated
+// with what those became: Shape.intersect + Intersections.hit (shape.zig:99-107, ray.zig:75-83),
+// Shape.normalAt (shape.zig:84-97) and calc.lighting with in_shadow = false (calc.zig:26-73).
+// out_rgb: canvas_size^2 * 3 doubles, row-major, black where the ray misses (Canvas.init zero-fills,
+// canvas.zig:12-22); out_rays (optional): the ray of every pixel, 6 doubles each.
+inline void drawSphere(uint64_t canvas_size, double* out_rgb, double* out_rays) {
+    Shape shape;
+    shape.geo = GEO_SPHERE;
+    shape.transform = Mat4::identity();
+    shape.material.color = {1.0, 0.2, 1.0};  // draw_sphere.zig:30-32
+    const Vec4 origin = initPoint(0, 0, -5);
+    const double wall_z = 10.0;
+    const double wall_size = 7.0;
+    const double pixel_size = wall_size / (double)canvas_size;
+    const double half = 0.5 * wall_size;
+    PointLight light;
+    light.intensity = {1, 1, 1};
+    light.position = initPoint(-10, 10, -10);
+    for (uint64_t y = 0; y < canvas_size; ++y) {
+        const double world_y = half - (double)y * pixel_size;
+        for (uint64_t x = 0; x < canvas_size; ++x) {
+            const double world_x = -half + (double)x * pixel_size;
+            const Vec4 wall_pos = initPoint(world_x, world_y, wall_z);
+            const Vec4 ray_dir = wall_pos.sub(origin).normalize();
+            const Ray ray{origin, ray_dir};
+            double* px = out_rgb + (y * canvas_size + x) * 3;
+            px[0] = px[1] = px[2] = 0.0;
+            if (out_rays) {
+                double* r = out_rays + (y * canvas_size + x) * 6;
+                r[0] = origin.x, r[1] = origin.y, r[2] = origin.z;
+                r[3] = ray_dir.x, r[4] = ray_dir.y, r[5] = ray_dir.z;
+            }
+            double ts[2];
+            const int n = intersectShape(shape, ray, ts);
+            Intersections xs;
+            for (int k = 0; k < n; ++k) xs.list.push_back({ts[k], shape});
+            const auto hit = xs.hit();
+            if (hit.has_value()) {
+                const Vec4 point = ray.position(hit->t);
+                const Vec4 normal = normalAt(hit->object, point);
+                const Vec4 eye = ray_dir.negate();
+                const Color color = lighting(hit->object, light, point, eye, normal, false);
+                px[0] = color.red, px[1] = color.green, px[2] = color.blue;
+            }
+        }
+    }
+}
+
 // ppm.zig:6-9
 inline uint8_t byteColorValue(double val) {
     double v = val * 256.0;

@@ -156,6 +156,12 @@ int orc_ray_for_pixel(const RtcCameraDesc* camera, uint64_t x, uint64_t y, doubl
     return 0;
 }
 
+// The loop of draw_sphere.zig:38-83 on a canvas_size x canvas_size canvas; out_rays may be NULL.
+int orc_draw_sphere(uint64_t canvas_size, double* out_rgb, double* out_rays) {
+    orc::drawSphere(canvas_size, out_rgb, out_rays);
+    return 0;
+}
+
 // std.math.pow as restated in rtc_oracle.hpp.
 double orc_pow(double x, double y) { return orc::zigmath::pow(x, y); }
 

@@ -28,6 +28,15 @@ def default_world():
     return World.init_default()
 
 
+def draw_sphere_world():
+    """The world of draw_sphere.zig:30-48 (the Ch. 6 plumbing program): one unit sphere of colour
+    (1, 0.2, 1) with the default material, one white light at (-10, 10, -10)."""
+    world = World()
+    world.light = PointLight(init_point(-10, 10, -10), Color(1, 1, 1))
+    world.objects.append(Shape("sphere", Mat4.identity(), Material(color=Color(1.0, 0.2, 1.0))))
+    return world
+
+
 def draw_world_scene(hsize=900, vsize=450):
     """World and camera of draw_world.zig:29-192.  The reference renders 900x450
     (draw_world.zig:32); other resolutions only change hsize/vsize, the aspect rule of

@@ -39,6 +39,7 @@ def lib():
         L.orc_color_at.argtypes = [sp, u64, lp, dp, u64, i32, i32, dp, st]
         L.orc_mat4_inverse.argtypes = [dp, dp, dp]
         L.orc_ray_for_pixel.argtypes = [cp, u64, u64, dp]
+        L.orc_draw_sphere.argtypes = [u64, dp, dp]
         L.orc_pow.argtypes = [C.c_double, C.c_double]
         L.orc_pow.restype = C.c_double
         L.orc_quantize_u8.argtypes = [dp, u64, C.POINTER(C.c_uint8)]
@@ -100,6 +101,14 @@ def ray_for_pixel(camera, x, y):
     out = np.empty(6, dtype=np.float64)
     lib().orc_ray_for_pixel(C.byref(cd), x, y, _dptr(out))
     return out
+
+
+def draw_sphere(canvas_size=100):
+    """draw_sphere.zig:38-83: (canvas (n, n, 3), rays (n*n, 6))."""
+    out = np.empty((canvas_size, canvas_size, 3), dtype=np.float64)
+    rays = np.empty((canvas_size * canvas_size, 6), dtype=np.float64)
+    assert lib().orc_draw_sphere(canvas_size, _dptr(out), _dptr(rays)) == 0
+    return out, rays
 
 
 def zig_pow(x, y):

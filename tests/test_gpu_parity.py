@@ -640,6 +640,73 @@ def test_full_size_frame_properties():
     assert st.pixels == hs * vs and st.radiance_rays > st.pixels
 
 
+def test_draw_sphere_plumbing_configuration():
+    """draw_sphere.zig:38-83 at 100x100: the 10 000 corner-sampled rays of the program through
+    rtc_color_at on its one-sphere world.  Identical to calc.worldColorAt of the oracle; against
+    the program's own canvas (lighting at the hit point, no shadow test) the silhouette is the
+    same and the colours differ by the 1e-4 surface offset only."""
+    canvas, rays = O.draw_sphere(100)
+    w = scenes.draw_sphere_world()
+    with scene_of(w) as sc:
+        st = D.RtcStats()
+        got = sc.color_at(rays, 5, st)
+        assert st.radiance_rays == 10000 and st.shadow_rays == st.shaded_hits
+    assert_identical(got, O.color_at(w, rays, 5, O.LITERAL), "draw_sphere rays")
+    got = got.reshape(100, 100, 3)
+    assert np.array_equal(np.any(got != 0, axis=2), np.any(canvas != 0, axis=2))
+    assert np.abs(got - canvas).max() < 2e-3
+    assert np.array_equal(byte_color_values(got) != 0, byte_color_values(canvas) != 0)
+
+
+def test_frame_of_7680x4320_in_2_4_8_way_partitions():
+    """The largest configuration: the Ch. 11 scene at 7680x4320 rendered once as a whole and as 2-,
+    4- and 8-way interleaved partitions on this one GPU (one tile buffer per rank, as each GPU of a
+    node would hold), scattered back on the device in f64 and in 8 bits: every assembly equals the
+    single-pass canvas, whose sampled rows equal the oracle's."""
+    import torch
+
+    hs, vs = 7680, 4320
+    w, c = scenes.draw_world_scene(hs, vs)
+    cd = c.desc()
+    dev = torch.device("cuda", 0)
+    n = hs * vs * 3
+    with scene_of(w) as sc:
+        full = torch.empty(n, dtype=torch.float64, device=dev)
+        st = D.RtcStats()
+        sc.render_device(cd, 5, full.data_ptr(), 0, 1, None, st)
+        assert st.pixels == hs * vs
+        q_full = torch.empty(n, dtype=torch.uint8, device=dev)
+        native.quantize_u8_device(full.data_ptr(), n, q_full.data_ptr())
+        canvas = torch.empty_like(full)
+        q = torch.empty_like(q_full)
+        for ranks in (2, 4, 8):
+            n0 = native.tile_buffer_doubles(cd, 0, ranks)
+            gathered = torch.empty((ranks, n0), dtype=torch.float64, device=dev)
+            rays = 0
+            for r in range(ranks):
+                s2 = D.RtcStats()
+                sc.render_device(cd, 5, gathered[r].data_ptr(), r, ranks, None, s2)
+                rays += s2.radiance_rays
+            assert rays == st.radiance_rays, ranks
+            canvas.fill_(-1.0)
+            native.deinterleave_device(cd, ranks, n0, gathered.data_ptr(), canvas.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(canvas, full), f"{ranks}-way f64 assembly"
+            gq = torch.empty((ranks, n0), dtype=torch.uint8, device=dev)
+            native.quantize_u8_device(gathered.data_ptr(), ranks * n0, gq.data_ptr())
+            q.fill_(77)
+            native.deinterleave_u8_device(cd, ranks, n0, gq.data_ptr(), q.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(q, q_full), f"{ranks}-way 8-bit assembly"
+            del gathered, gq
+        sel = slice(11, vs, 96)
+        host_rows = full.view(vs, hs, 3)[sel].cpu().numpy()
+        q_rows = q_full.view(vs, hs, 3)[sel].cpu().numpy()
+    cpu = O.render(w, c, 5, O.STREAMING, rows=(11, vs, 96))
+    assert_identical(host_rows, cpu[sel], "8K sampled rows")
+    assert np.array_equal(q_rows, byte_color_values(cpu[sel]))
+
+
 def test_render_u8_gives_the_bytes_the_ppm_writer_prints():
     """rtc_render_u8 = Camera.render + byteColorValue (ppm.zig:6-9) against the oracle's canvas
     quantised on the host, on a small and a ragged canvas, with stats, alternating with rtc_render
