@@ -216,6 +216,24 @@ int rtc_render_device_noalloc(RtcScene* scene, const RtcCameraDesc* camera, int3
                               uint32_t tile_rank, uint32_t tile_ranks, void* d_out_rgb,
                               void* hip_stream, RtcStats* stats);
 
+/* rtc_render_device with the rank's pixels stored at their final place: d_canvas_rgb is the full
+ * row-major canvas (hsize*vsize*3 doubles) and this call fills the pixels of the tiles t with
+ * t % tile_ranks == tile_rank, leaving the others untouched.  The canvas may live in another GPU's
+ * memory that the current GPU can address (peer access within one process, or an IPC mapping):
+ * N ranks then assemble one canvas with no tile buffers, no gather and no de-interleave pass.
+ * No counterpart in the reference (camera.zig:77-86 is one serial loop). */
+int rtc_render_device_to_canvas(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth,
+                                uint32_t tile_rank, uint32_t tile_ranks, void* d_canvas_rgb,
+                                void* hip_stream, RtcStats* stats);
+
+/* One rank's dense tile buffer (as rtc_render_device fills it, or its 8-bit image after
+ * rtc_quantize_u8_device) into the row-major canvas: the sender's half of a gather.  The canvas
+ * may be peer memory.  Device pointers. */
+int rtc_scatter_tiles_device(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks,
+                             const void* d_tiles, void* d_canvas_rgb, void* hip_stream);
+int rtc_scatter_tiles_u8_device(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks,
+                                const void* d_tiles_u8, void* d_canvas_u8, void* hip_stream);
+
 /* Number of doubles rtc_render_device writes into for (camera, tile_rank, tile_ranks). */
 int rtc_tile_buffer_doubles(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks,
                             uint64_t* out_doubles);
@@ -252,6 +270,52 @@ int rtc_render_u8(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, u
  * this call then expects the tiled layout and is not needed. */
 int rtc_deinterleave_u8_device(const RtcCameraDesc* camera, uint32_t tile_ranks, uint64_t per_rank_bytes,
                                const void* d_gathered_u8, void* d_out_u8, void* hip_stream);
+
+/* ---- Camera.render over several GPUs from one process ------------------------------------
+ * The body of Camera.render (camera.zig:74-89) for a caller that is one thread of one process
+ * (the Zig program) and wants the GPUs of a node: the library holds one replica of the world per
+ * rank, deals the RTC_TILE_W x RTC_TILE_H tiles of the canvas round-robin to the ranks
+ * (rank = tile % n_ranks), runs every rank's render kernel concurrently on its own stream and
+ * assembles the row-major canvas on rank 0's GPU.  The canvas is value-identical to rtc_render's
+ * for every rank count and mode.  No counterpart in the reference (it is single-threaded).
+ *
+ * rtc_multi_create: devices[r] is the HIP device of rank r; devices == NULL maps rank r onto
+ * visible device r % device_count (so n_ranks may exceed the number of GPUs: ranks then share a
+ * GPU, which is how a one-GPU machine rehearses an eight-rank frame). */
+typedef struct RtcMulti RtcMulti;
+#define RTC_MULTI_MAX_RANKS 64
+int rtc_multi_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLightDesc* light,
+                     const int32_t* devices, uint32_t n_ranks, RtcMulti** out_multi);
+int rtc_multi_destroy(RtcMulti* multi);
+int rtc_multi_rank_device(const RtcMulti* multi, uint32_t rank, int32_t* out_device);
+
+/* How the ranks' pixels reach rank 0's canvas. */
+#define RTC_MULTI_PEER_STORES 0  /* render kernels store into rank 0's canvas through peer access */
+#define RTC_MULTI_PEER_SCATTER 1 /* dense tile buffers; each rank scatters its tiles into rank 0's
+                                    canvas through peer access after rendering (8-bit: after
+                                    quantising, so 3 instead of 24 bytes per pixel cross the link) */
+#define RTC_MULTI_RCCL_GATHER 2  /* dense tile buffers, RCCL send/recv to rank 0 (single process,
+                                    ncclCommInitAll), de-interleave kernel on rank 0 */
+
+/* Device-side phases of one call, in milliseconds: from the first launch until every rank's pixels
+ * are on rank 0's GPU (rendering and the transfers, which overlap in the peer modes), then rank
+ * 0's own assembly (de-interleave and/or quantisation); device_ms is the host's wall clock from
+ * the call until the canvas is complete on rank 0's GPU, to_host_ms the copy to the caller. */
+typedef struct RtcMultiTiming {
+    double render_and_transfer_ms;
+    double assemble_ms;
+    double device_ms;
+    double to_host_ms;
+} RtcMultiTiming;
+
+/* Camera.render on all ranks.  out_rgb: host memory, hsize*vsize*3 doubles as rtc_render; NULL
+ * leaves the canvas on rank 0's GPU (timing runs).  stats (may be NULL) receives the sums over the
+ * ranks and the longest kernel; asking for stats serialises the ranks.  timing may be NULL. */
+int rtc_render_multi(RtcMulti* multi, const RtcCameraDesc* camera, int32_t depth, int32_t mode,
+                     double* out_rgb, RtcStats* stats, RtcMultiTiming* timing);
+/* The same with byteColorValue (ppm.zig:6-9) applied on the GPUs, as rtc_render_u8. */
+int rtc_render_multi_u8(RtcMulti* multi, const RtcCameraDesc* camera, int32_t depth, int32_t mode,
+                        uint8_t* out_rgb8, RtcStats* stats, RtcMultiTiming* timing);
 
 /* ---- diagnostics (used by the parity tests) ------------------------------ */
 

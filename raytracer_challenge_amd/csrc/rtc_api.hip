@@ -809,6 +809,7 @@ int fill_camera_job(const RtcCameraDesc* camera, int32_t depth, uint32_t tile_ra
     tile_counts(camera->hsize, camera->vsize, tile_rank, tile_ranks, &job->tiles_x, &job->tiles_total, &local_tiles);
     job->tile_rank = tile_rank;
     job->tile_ranks = tile_ranks;
+    job->out_row_major = tile_ranks == 1 ? 1u : 0u;
     job->rays = nullptr;
     job->total = (uint32_t)(local_tiles * RTC_TILE_W * RTC_TILE_H);
     job->depth = depth;
@@ -860,6 +861,14 @@ int scratch_of_current_device(ScratchSlot** out) {
 }
 
 }  // namespace
+
+namespace rtc {
+int set_error(int code, const char* message) { return fail(code, message); }
+int set_hip_error(const char* what, hipError_t e) { return fail_hip(what, e); }
+int copy_device_to_host(RtcScene* scene, const void* d_src, void* dst, size_t bytes) {
+    return copy_canvas_to_host(scene, d_src, dst, bytes);
+}
+}  // namespace rtc
 
 extern "C" {
 
@@ -1143,6 +1152,42 @@ int rtc_render_device(RtcScene* scene, const RtcCameraDesc* camera, int32_t dept
     return run_job(scene, job, (hipStream_t)hip_stream, stats, pixels);
 }
 
+int rtc_render_device_to_canvas(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, uint32_t tile_rank,
+                                uint32_t tile_ranks, void* d_canvas_rgb, void* hip_stream, RtcStats* stats) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (!valid_stream_and_ptr(d_canvas_rgb)) return fail(RTC_ERR_INVALID_ARGUMENT, "d_canvas_rgb is NULL");
+    rtc::DevJob job{};
+    uint64_t local_pixels = 0;
+    if (int rc = fill_camera_job(camera, depth, tile_rank, tile_ranks, &job, &local_pixels)) return rc;
+    job.out = (double*)d_canvas_rgb;
+    job.out_row_major = 1;
+    if (int rc = plan_tile_order(scene, camera, &job, local_pixels / (RTC_TILE_W * RTC_TILE_H), (hipStream_t)hip_stream))
+        return rc;
+    return run_job(scene, job, (hipStream_t)hip_stream, stats, local_pixels);
+}
+
+int rtc_scatter_tiles_device(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks, const void* d_tiles,
+                             void* d_canvas_rgb, void* hip_stream) {
+    if (int rc = check_camera(camera)) return rc;
+    if (!d_tiles || !d_canvas_rgb) return fail(RTC_ERR_INVALID_ARGUMENT, "device pointer is NULL");
+    if (tile_ranks == 0 || tile_rank >= tile_ranks)
+        return fail(RTC_ERR_INVALID_ARGUMENT, "tile_rank must be < tile_ranks and tile_ranks >= 1");
+    HIP_TRY(rtc::launch_scatter_tiles((const double*)d_tiles, tile_rank, tile_ranks, (uint32_t)camera->hsize,
+                                      (uint32_t)camera->vsize, (double*)d_canvas_rgb, (hipStream_t)hip_stream));
+    return RTC_OK;
+}
+
+int rtc_scatter_tiles_u8_device(const RtcCameraDesc* camera, uint32_t tile_rank, uint32_t tile_ranks,
+                                const void* d_tiles_u8, void* d_canvas_u8, void* hip_stream) {
+    if (int rc = check_camera(camera)) return rc;
+    if (!d_tiles_u8 || !d_canvas_u8) return fail(RTC_ERR_INVALID_ARGUMENT, "device pointer is NULL");
+    if (tile_ranks == 0 || tile_rank >= tile_ranks)
+        return fail(RTC_ERR_INVALID_ARGUMENT, "tile_rank must be < tile_ranks and tile_ranks >= 1");
+    HIP_TRY(rtc::launch_scatter_tiles_u8((const uint8_t*)d_tiles_u8, tile_rank, tile_ranks, (uint32_t)camera->hsize,
+                                         (uint32_t)camera->vsize, (uint8_t*)d_canvas_u8, (hipStream_t)hip_stream));
+    return RTC_OK;
+}
+
 int rtc_render_device_noalloc(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, uint32_t tile_rank,
                               uint32_t tile_ranks, void* d_out_rgb, void* hip_stream, RtcStats* stats) {
     if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
@@ -1261,6 +1306,7 @@ int rtc_color_at(RtcScene* scene, const double* rays, uint64_t n_rays, int32_t d
         job.depth = depth;
         job.out = d_out;
         job.tile_ranks = 1;
+        job.out_row_major = 1;
         rc = run_job(scene, job, nullptr, stats, n_rays);
     }
     if (rc == RTC_OK) {

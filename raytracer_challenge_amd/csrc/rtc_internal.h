@@ -95,6 +95,10 @@ struct DevJob {
     uint32_t hsize, vsize;
     // tile partition (see rtc_render_device in the public header)
     uint32_t tiles_x, tiles_total, tile_rank, tile_ranks;
+    // 1: `out` is the full row-major canvas (always so with one rank; with several ranks every rank
+    // then stores its pixels at their final place, possibly in a peer GPU's memory); 0: the rank's
+    // dense tile buffer
+    uint32_t out_row_major;
     // explicit rays instead of camera rays (rtc_color_at): 6 doubles per ray, or nullptr
     const double* rays;
     uint32_t total;  // number of work items: local tile pixels (padding included) or rays
@@ -114,8 +118,19 @@ hipError_t launch_deinterleave(const double* gathered, uint64_t per_rank_doubles
                                uint32_t hsize, uint32_t vsize, double* out, hipStream_t stream);
 hipError_t launch_deinterleave_u8(const uint8_t* gathered, uint64_t per_rank_bytes, uint32_t tile_ranks,
                                   uint32_t hsize, uint32_t vsize, uint8_t* out, hipStream_t stream);
+// One rank's dense tile buffer (f64 or 8-bit values, three per pixel) into the row-major canvas.
+hipError_t launch_scatter_tiles(const double* tiles, uint32_t tile_rank, uint32_t tile_ranks, uint32_t hsize,
+                                uint32_t vsize, double* canvas, hipStream_t stream);
+hipError_t launch_scatter_tiles_u8(const uint8_t* tiles, uint32_t tile_rank, uint32_t tile_ranks, uint32_t hsize,
+                                   uint32_t vsize, uint8_t* canvas, hipStream_t stream);
 hipError_t launch_quantize(const double* rgb, uint64_t n, uint8_t* out, hipStream_t stream);
 hipError_t launch_arith_probe(const double* a, const double* b, uint64_t n, double* out_div, double* out_sqrt,
                               double* out_pow, hipStream_t stream);
+
+
+// Host-side helpers of rtc_api.hip used by the multi-GPU orchestration (rtc_multi.hip).
+int set_error(int code, const char* message);            // records the thread's last error, returns code
+int set_hip_error(const char* what, hipError_t e);       // same for a failed HIP call
+int copy_device_to_host(RtcScene* scene, const void* d_src, void* dst, size_t bytes);  // staged, see copy_canvas_to_host
 
 }  // namespace rtc

@@ -925,7 +925,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     blk_py0 = (gt / job.tiles_x) * RTC_TILE_H;
                     blk_valid = gt < job.tiles_total;
                     // canvas pixel of the block's first pixel, or its slot in the rank's dense tile buffer
-                    blk_out0 = job.tile_ranks == 1 ? blk_py0 * job.hsize + blk_px0 : lt * tile_px + blk * 8;
+                    blk_out0 = job.out_row_major ? blk_py0 * job.hsize + blk_px0 : lt * tile_px + blk * 8;
                 }
             }
             const uint32_t avail = loc_end - loc_next;
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                         const V3 pixel = xform_point(cam_inv, V3{world_x, world_y, -1.0});
                         ro = cam_origin;
                         rd = normalize3(V3{pixel.x - cam_origin.x, pixel.y - cam_origin.y, pixel.z - cam_origin.z});
-                        const uint32_t row_stride = job.tile_ranks == 1 ? job.hsize : (uint32_t)RTC_TILE_W;
+                        const uint32_t row_stride = job.out_row_major ? job.hsize : (uint32_t)RTC_TILE_W;
                         out_pixel = blk_out0 + ty * row_stride + tx;
                         got_work = true;
                     }
@@ -1357,6 +1357,29 @@ __global__ __launch_bounds__(kBlock) void deinterleave_kernel(const T* __restric
     }
 }
 
+// One rank's dense tile buffer into the row-major canvas (which may be a peer GPU's memory: the
+// sender scatters, so the receiver needs no gather buffer and no pass of its own).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scatter_tiles_kernel(const T* __restrict__ tiles, uint32_t tile_rank,
+                                                               uint32_t tile_ranks, uint32_t hsize, uint32_t vsize,
+                                                               uint32_t tiles_x, uint32_t local_tiles,
+                                                               T* __restrict__ canvas) {
+    const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
+    const uint64_t total = (uint64_t)local_tiles * tile_px;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t lt = (uint32_t)(g / tile_px), within = (uint32_t)(g % tile_px);
+        const uint32_t gt = lt * tile_ranks + tile_rank;
+        const uint32_t px = (gt % tiles_x) * RTC_TILE_W + within % RTC_TILE_W;
+        const uint32_t py = (gt / tiles_x) * RTC_TILE_H + within / RTC_TILE_W;
+        if (px >= hsize || py >= vsize) continue;
+        const T* src = tiles + g * 3;
+        T* dst = canvas + ((uint64_t)py * hsize + px) * 3;
+        dst[0] = src[0];
+        dst[1] = src[1];
+        dst[2] = src[2];
+    }
+}
+
 // byteColorValue (ppm.zig:6-9): clamp(v*256, 0, 255) with Zig's min/max, then truncate.
 __global__ __launch_bounds__(kBlock) void quantize_kernel(const double* __restrict__ rgb, uint64_t n,
                                                           uint8_t* __restrict__ out) {
@@ -1454,6 +1477,33 @@ hipError_t launch_deinterleave(const double* gathered, uint64_t per_rank_doubles
 hipError_t launch_deinterleave_u8(const uint8_t* gathered, uint64_t per_rank_bytes, uint32_t tile_ranks, uint32_t hsize,
                                   uint32_t vsize, uint8_t* out, hipStream_t stream) {
     return launch_deinterleave_t<uint8_t>(gathered, per_rank_bytes, tile_ranks, hsize, vsize, out, stream);
+}
+
+namespace {
+template <typename T>
+hipError_t launch_scatter_tiles_t(const T* tiles, uint32_t tile_rank, uint32_t tile_ranks, uint32_t hsize, uint32_t vsize,
+                                  T* canvas, hipStream_t stream) {
+    const uint32_t tiles_x = (hsize + RTC_TILE_W - 1) / RTC_TILE_W;
+    const uint32_t tiles_y = (vsize + RTC_TILE_H - 1) / RTC_TILE_H;
+    const uint64_t tiles_total = (uint64_t)tiles_x * tiles_y;
+    const uint64_t local_tiles = tiles_total > tile_rank ? (tiles_total - tile_rank + tile_ranks - 1) / tile_ranks : 0;
+    if (local_tiles == 0) return hipSuccess;
+    uint64_t blocks = (local_tiles * RTC_TILE_W * RTC_TILE_H + kBlock - 1) / kBlock;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(scatter_tiles_kernel<T>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, tiles, tile_rank, tile_ranks,
+                       hsize, vsize, tiles_x, (uint32_t)local_tiles, canvas);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_scatter_tiles(const double* tiles, uint32_t tile_rank, uint32_t tile_ranks, uint32_t hsize,
+                                uint32_t vsize, double* canvas, hipStream_t stream) {
+    return launch_scatter_tiles_t<double>(tiles, tile_rank, tile_ranks, hsize, vsize, canvas, stream);
+}
+
+hipError_t launch_scatter_tiles_u8(const uint8_t* tiles, uint32_t tile_rank, uint32_t tile_ranks, uint32_t hsize,
+                                   uint32_t vsize, uint8_t* canvas, hipStream_t stream) {
+    return launch_scatter_tiles_t<uint8_t>(tiles, tile_rank, tile_ranks, hsize, vsize, canvas, stream);
 }
 
 hipError_t launch_quantize(const double* rgb, uint64_t n, uint8_t* out, hipStream_t stream) {

@@ -25,6 +25,11 @@ RTC_PATTERN_CHECKERS = 4
 
 RTC_ACCEL_NONE = 0
 RTC_ACCEL_BVH = 1
+RTC_NOALLOC_MAX_TILES = 262144
+RTC_MULTI_MAX_RANKS = 64
+RTC_MULTI_PEER_STORES = 0
+RTC_MULTI_PEER_SCATTER = 1
+RTC_MULTI_RCCL_GATHER = 2
 RTC_TILE_W = 64
 RTC_TILE_H = 8
 
@@ -96,6 +101,18 @@ class RtcStats(C.Structure):
         ("kernel_ms", C.c_double),
         ("sphere_bound_skips", C.c_uint64),
         ("plane_side_skips", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class RtcMultiTiming(C.Structure):
+    _fields_ = [
+        ("render_and_transfer_ms", C.c_double),
+        ("assemble_ms", C.c_double),
+        ("device_ms", C.c_double),
+        ("to_host_ms", C.c_double),
     ]
 
     def as_dict(self):

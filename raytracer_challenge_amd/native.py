@@ -51,6 +51,17 @@ def lib():
     L.rtc_render_u8.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, C.POINTER(C.c_uint8), C.POINTER(D.RtcStats)]
     L.rtc_render_device.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
     L.rtc_render_device_noalloc.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
+    L.rtc_render_device_to_canvas.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
+    L.rtc_scatter_tiles_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, vp, vp, vp]
+    L.rtc_scatter_tiles_u8_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, vp, vp, vp]
+    L.rtc_multi_create.argtypes = [C.POINTER(D.RtcShapeDesc), u64, C.POINTER(D.RtcLightDesc), C.POINTER(i32), u32,
+                                   C.POINTER(vp)]
+    L.rtc_multi_destroy.argtypes = [vp]
+    L.rtc_multi_rank_device.argtypes = [vp, u32, C.POINTER(i32)]
+    L.rtc_render_multi.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, i32, dp, C.POINTER(D.RtcStats),
+                                   C.POINTER(D.RtcMultiTiming)]
+    L.rtc_render_multi_u8.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, i32, C.POINTER(C.c_uint8),
+                                      C.POINTER(D.RtcStats), C.POINTER(D.RtcMultiTiming)]
     L.rtc_tile_buffer_doubles.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, C.POINTER(u64)]
     L.rtc_deinterleave_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
     L.rtc_deinterleave_u8_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
@@ -78,6 +89,14 @@ EXPORTS = (
     "rtc_render_u8",
     "rtc_render_device",
     "rtc_render_device_noalloc",
+    "rtc_render_device_to_canvas",
+    "rtc_scatter_tiles_device",
+    "rtc_scatter_tiles_u8_device",
+    "rtc_multi_create",
+    "rtc_multi_destroy",
+    "rtc_multi_rank_device",
+    "rtc_render_multi",
+    "rtc_render_multi_u8",
     "rtc_tile_buffer_doubles",
     "rtc_deinterleave_device",
     "rtc_deinterleave_u8_device",
@@ -137,6 +156,14 @@ def deinterleave_device(camera_desc, tile_ranks, per_rank_doubles, d_gathered, d
 def deinterleave_u8_device(camera_desc, tile_ranks, per_rank_bytes, d_gathered_u8, d_out_u8, stream=None):
     check(lib().rtc_deinterleave_u8_device(C.byref(camera_desc), tile_ranks, per_rank_bytes, d_gathered_u8, d_out_u8,
                                            stream))
+
+
+def scatter_tiles_device(camera_desc, tile_rank, tile_ranks, d_tiles, d_canvas, stream=None):
+    check(lib().rtc_scatter_tiles_device(C.byref(camera_desc), tile_rank, tile_ranks, d_tiles, d_canvas, stream))
+
+
+def scatter_tiles_u8_device(camera_desc, tile_rank, tile_ranks, d_tiles_u8, d_canvas_u8, stream=None):
+    check(lib().rtc_scatter_tiles_u8_device(C.byref(camera_desc), tile_rank, tile_ranks, d_tiles_u8, d_canvas_u8, stream))
 
 
 def quantize_u8_device(d_rgb, n_values, d_out_u8, stream=None):
@@ -213,10 +240,68 @@ class Scene:
             )
         )
 
+    def render_device_to_canvas(self, camera_desc, depth, d_canvas, tile_rank=0, tile_ranks=1, stream=None, stats=None):
+        """rtc_render_device_to_canvas: this rank's tiles straight into the full row-major canvas."""
+        sp = C.byref(stats) if stats is not None else None
+        check(
+            lib().rtc_render_device_to_canvas(
+                self._h, C.byref(camera_desc), int(depth), tile_rank, tile_ranks, C.c_void_p(d_canvas), stream, sp
+            )
+        )
+
     def color_at(self, rays, depth=5, stats=None):
         """rtc_color_at: rays is (n, 6) [origin xyz, direction xyz]; returns (n, 3)."""
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         out = np.empty((rays.shape[0], 3), dtype=np.float64)
         sp = C.byref(stats) if stats is not None else None
         check(lib().rtc_color_at(self._h, _dptr(rays), rays.shape[0], int(depth), _dptr(out), sp))
+        return out
+
+
+class Multi:
+    """A world replicated over the ranks of one process (rtc_multi_create / rtc_multi_destroy)."""
+
+    def __init__(self, shape_descs, n_shapes, light_desc, n_ranks, devices=None):
+        self._h = C.c_void_p(None)
+        self.n_ranks = int(n_ranks)
+        dev = (C.c_int32 * self.n_ranks)(*devices) if devices is not None else None
+        check(lib().rtc_multi_create(shape_descs, int(n_shapes), C.byref(light_desc), dev, self.n_ranks, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().rtc_multi_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rank_device(self, rank):
+        d = C.c_int32(-1)
+        check(lib().rtc_multi_rank_device(self._h, rank, C.byref(d)))
+        return d.value
+
+    def render(self, camera_desc, depth=5, mode=D.RTC_MULTI_PEER_STORES, stats=None, timing=None, to_host=True):
+        """rtc_render_multi: the (vsize, hsize, 3) float64 canvas, or None with to_host=False."""
+        out = np.empty((camera_desc.vsize, camera_desc.hsize, 3), dtype=np.float64) if to_host else None
+        check(lib().rtc_render_multi(self._h, C.byref(camera_desc), int(depth), int(mode),
+                                     _dptr(out) if to_host else None,
+                                     C.byref(stats) if stats is not None else None,
+                                     C.byref(timing) if timing is not None else None))
+        return out
+
+    def render_u8(self, camera_desc, depth=5, mode=D.RTC_MULTI_PEER_STORES, stats=None, timing=None, to_host=True):
+        out = np.empty((camera_desc.vsize, camera_desc.hsize, 3), dtype=np.uint8) if to_host else None
+        check(lib().rtc_render_multi_u8(self._h, C.byref(camera_desc), int(depth), int(mode),
+                                        out.ctypes.data_as(C.POINTER(C.c_uint8)) if to_host else None,
+                                        C.byref(stats) if stats is not None else None,
+                                        C.byref(timing) if timing is not None else None))
         return out

@@ -1,0 +1,130 @@
+"""Camera.render over several ranks from one process (rtc_multi_create / rtc_render_multi): every
+rank count and transfer mode must give the canvas of the single-GPU call, value for value.
+
+The ranks are mapped onto however many GPUs the machine shows (rank r on GPU r % count): on a
+one-GPU box all ranks share the card, which exercises the partition, the per-rank streams and
+events, the in-place stores, the scatter kernels and the de-interleave, but not a transfer
+between GPUs (peer access and the RCCL send/recv are then between a GPU and itself, i.e. absent).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from raytracer_challenge_amd import byte_color_values, descs as D, native, scenes
+
+pytestmark = pytest.mark.gpu
+
+MODES = (D.RTC_MULTI_PEER_STORES, D.RTC_MULTI_PEER_SCATTER, D.RTC_MULTI_RCCL_GATHER)
+
+
+def _multi(world, ranks, devices=None):
+    return native.Multi(world.shape_descs(), len(world.objects), world.light_desc(), ranks, devices)
+
+
+@pytest.mark.parametrize("ranks", [1, 2, 3, 4, 8])
+def test_render_multi_equals_the_single_gpu_canvas(ranks):
+    w, c = scenes.draw_world_scene(333, 97)  # ragged: 6 x 13 tiles, cut at the right and the bottom
+    cd = c.desc()
+    want = O.render(w, c, 5, O.STREAMING)
+    want_u8 = byte_color_values(want)
+    with native.Scene(w.shape_descs(), len(w.objects), w.light_desc()) as sc:
+        st1 = D.RtcStats()
+        assert np.array_equal(sc.render(cd, 5, st1), want)
+    with _multi(w, ranks) as m:
+        assert [m.rank_device(r) for r in range(ranks)] == [r % native.device_count() for r in range(ranks)]
+        for mode in MODES:
+            st, tm = D.RtcStats(), D.RtcMultiTiming()
+            got = m.render(cd, 5, mode, st, tm)
+            assert np.array_equal(got, want), f"{ranks} ranks, mode {mode}, f64"
+            for k in ("radiance_rays", "shadow_rays", "sphere_hits", "plane_hits", "shaded_hits", "pixels"):
+                assert getattr(st, k) == getattr(st1, k), (k, ranks, mode)
+            assert tm.device_ms > 0 and tm.render_and_transfer_ms > 0
+            # without statistics the ranks run concurrently; twice, to reuse every buffer
+            assert np.array_equal(m.render(cd, 5, mode), want), f"{ranks} ranks, mode {mode}, concurrent"
+            assert np.array_equal(m.render_u8(cd, 5, mode), want_u8), f"{ranks} ranks, mode {mode}, 8-bit"
+            assert np.array_equal(m.render_u8(cd, 5, mode), want_u8)
+            assert np.array_equal(m.render(cd, 5, mode), want)
+
+
+def test_render_multi_at_the_headline_size_and_with_changing_cameras():
+    """3840x2160 over 8 ranks in every mode against the single-GPU canvas; then a smaller and a
+    larger camera on the same handle (buffers shrink-to-fit never, grow on demand)."""
+    w, c = scenes.draw_world_scene(3840, 2160)
+    cd = c.desc()
+    with native.Scene(w.shape_descs(), len(w.objects), w.light_desc()) as sc:
+        want = sc.render(cd, 5)
+        want_u8 = sc.render_u8(cd, 5)
+    rows = slice(5, 2160, 240)
+    cpu = O.render(w, c, 5, O.STREAMING, rows=(5, 2160, 240))
+    assert np.array_equal(want[rows], cpu[rows])
+    with _multi(w, 8) as m:
+        for mode in MODES:
+            assert np.array_equal(m.render(cd, 5, mode), want), f"mode {mode}"
+            assert np.array_equal(m.render_u8(cd, 5, mode), want_u8), f"mode {mode} 8-bit"
+        for size in ((200, 100), (1920, 1080)):
+            w2, c2 = scenes.draw_world_scene(*size)
+            cpu = O.render(w2, c2, 5, O.STREAMING) if size[0] < 1000 else None
+            with native.Scene(w.shape_descs(), len(w.objects), w.light_desc()) as sc:
+                ref = sc.render(c2.desc(), 5)
+            if cpu is not None:
+                assert np.array_equal(ref, cpu)
+            for mode in MODES:
+                assert np.array_equal(m.render(c2.desc(), 5, mode), ref), (size, mode)
+        # canvas left on rank 0's GPU (timing runs)
+        tm = D.RtcMultiTiming()
+        assert m.render(cd, 5, D.RTC_MULTI_PEER_STORES, None, tm, to_host=False) is None
+        assert tm.to_host_ms < tm.device_ms + 1.0
+
+
+def test_render_multi_argument_errors():
+    w, c = scenes.draw_world_scene(64, 32)
+    with pytest.raises(native.RtcError) as e:
+        _multi(w, 0)
+    assert e.value.code == D.RTC_ERR_INVALID_ARGUMENT
+    with pytest.raises(native.RtcError) as e:
+        _multi(w, 2, devices=[0, native.device_count()])
+    assert e.value.code == D.RTC_ERR_INVALID_ARGUMENT
+    w.objects[0].transform.mat[1][1] = 0.0
+    w.objects[0].transform.mat[1][3] = 0.0
+    with pytest.raises(native.RtcError) as e:
+        _multi(w, 2)
+    assert e.value.code == D.RTC_ERR_SINGULAR_TRANSFORM
+    w, c = scenes.draw_world_scene(64, 32)
+    with _multi(w, 2) as m:
+        with pytest.raises(native.RtcError) as e:
+            m.render(c.desc(), 5, 7)
+        assert e.value.code == D.RTC_ERR_INVALID_ARGUMENT
+        with pytest.raises(native.RtcError) as e:
+            m.render(c.desc(), 17, D.RTC_MULTI_PEER_STORES)
+        assert e.value.code == D.RTC_ERR_TOO_LARGE
+        assert m.render(c.desc(), 5).shape == (32, 64, 3)
+
+
+def test_to_canvas_and_scatter_entry_points():
+    """rtc_render_device_to_canvas and rtc_scatter_tiles(_u8)_device on their own: three ranks fill
+    one canvas in place; three tile buffers are scattered into another; both equal the 1-rank canvas."""
+    import torch
+
+    hs, vs, ranks = 200, 43, 3
+    w, c = scenes.draw_world_scene(hs, vs)
+    cd = c.desc()
+    dev = torch.device("cuda", 0)
+    with native.Scene(w.shape_descs(), len(w.objects), w.light_desc()) as sc:
+        full = torch.empty(hs * vs * 3, dtype=torch.float64, device=dev)
+        sc.render_device(cd, 5, full.data_ptr())
+        inplace = torch.full_like(full, -1.0)
+        scattered = torch.full_like(full, -2.0)
+        q_scattered = torch.full((hs * vs * 3,), 9, dtype=torch.uint8, device=dev)
+        for r in range(ranks):
+            sc.render_device_to_canvas(cd, 5, inplace.data_ptr(), r, ranks)
+            n = native.tile_buffer_doubles(cd, r, ranks)
+            t = torch.empty(n, dtype=torch.float64, device=dev)
+            sc.render_device(cd, 5, t.data_ptr(), r, ranks)
+            native.scatter_tiles_device(cd, r, ranks, t.data_ptr(), scattered.data_ptr())
+            q = torch.empty(n, dtype=torch.uint8, device=dev)
+            native.quantize_u8_device(t.data_ptr(), n, q.data_ptr())
+            native.scatter_tiles_u8_device(cd, r, ranks, q.data_ptr(), q_scattered.data_ptr())
+            torch.cuda.synchronize()
+        assert torch.equal(inplace, full) and torch.equal(scattered, full)
+        host = full.cpu().numpy().reshape(vs, hs, 3)
+        assert np.array_equal(q_scattered.cpu().numpy().reshape(vs, hs, 3), byte_color_values(host))
