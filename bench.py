@@ -79,18 +79,18 @@ def executed_flops(st, groups):
     )
 
 
-def pmc_traffic(workload, n_gpus):
-    """Memory-side bytes per render_kernel launch, from the committed PMC passes of this same
-    command (hardware counters cannot be read inside a timed run); None when no pass covers
-    the workload."""
+def pmc_counters(workload, n_gpus):
+    """Hardware counters of one render_kernel launch from the committed PMC passes of this same
+    command (profiles/pmc_counters.json, written by scripts/pmc_to_json.py; hardware counters
+    cannot be read inside a timed run); None when no pass covers the workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
             entry = json.load(f).get(workload)
     except (OSError, ValueError):
         return None
     if not entry or entry.get("n_gpus") != n_gpus:
         return None
-    return entry["read_bytes"] + entry["write_bytes"]
+    return entry
 
 
 def cpu_baseline(world, camera, depth, budget_s=20.0):
@@ -105,6 +105,14 @@ def cpu_baseline(world, camera, depth, budget_s=20.0):
     import numpy as np
 
     n_pixels = camera.hsize * camera.vsize
+    # one core, and always the same one: the first the process is allowed on
+    pinned_to = None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, {allowed[0]})
+        pinned_to = allowed[0]
+    except (AttributeError, OSError):
+        allowed = None
 
     def run(mode, n_sample):
         # every k-th pixel of the frame in row-major order, k odd so that the samples do not line up in columns
@@ -122,6 +130,8 @@ def cpu_baseline(world, camera, depth, budget_s=20.0):
     s_rate, s_rays, s_dt, s_px, s_k = run(O.STREAMING, probe_n * budget_s * 0.25 / max(probe_dt, 1e-6))
     _, _, probe_dt, probe_n, _ = run(O.LITERAL, 16)
     l_rate, l_rays, l_dt, l_px, l_k = run(O.LITERAL, probe_n * budget_s * 0.7 / max(probe_dt, 1e-6))
+    if allowed:
+        os.sched_setaffinity(0, set(allowed))
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -141,6 +151,7 @@ def cpu_baseline(world, camera, depth, budget_s=20.0):
         "streaming_value": s_rate,
         "streaming_sample": f"every {s_k}th pixel: {s_px} pixels, {s_rays} radiance rays in {s_dt:.1f} s",
         "cpu_model": cpu_model,
+        "pinned_to_core": pinned_to,
         "host_cores_visible": os.cpu_count(),
     }
 
@@ -323,7 +334,58 @@ def main():
         rays_per_s = total["radiance_rays"] / (ms_per_step * 1e-3)
         # roofline of the dominant kernel (render_kernel) on THIS rank: algorithmic flops of
         # one launch / average launch duration from the HIP events above
-        achieved = local_flops / (kernel_ms * 1e-3) / 1e12
+        # `achieved` counts the flops the kernel EXECUTES for the reference's arithmetic (the model of
+        # executed_flops above); the reference's own count (54 per ray-sphere, 11 per ray-plane test,
+        # zeros and dismissed pairs included) is reported beside it as *_algorithmic
+        sec = kernel_ms * 1e-3
+        achieved = local_executed / sec / 1e12
+        achieved_alg = local_flops / sec / 1e12
+        frac_alg = achieved_alg / PEAK_FP64_NO_FMA_TFLOPS
+        pmc = pmc_counters(args.workload, world_size)
+        roofline = {
+            "bound": "fp64-valu",
+            "achieved": achieved,
+            "peak": PEAK_FP64_NO_FMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP64_NO_FMA_TFLOPS,
+            "traffic": (pmc["read_bytes"] + pmc["write_bytes"]) if pmc else None,
+            "kernel": "render_kernel",
+            "kernel_ms": kernel_ms,
+            "executed_flops_per_launch": local_executed,
+            "algorithmic_flops_per_launch": local_flops,
+            "achieved_algorithmic": achieved_alg,
+            # the reference's count can exceed what any kernel could execute at peak when most of it
+            # is products with exact zeros and pairs a bound dismisses: then it is no fraction of a peak
+            "frac_algorithmic": frac_alg if frac_alg <= 1.0 else None,
+            "peak_with_fma": PEAK_FP64_FMA_TFLOPS,
+            "frac_of_fma_peak": achieved / PEAK_FP64_FMA_TFLOPS,
+            "note": "compute-bound FP64 vector path (no dense contraction, so not MFMA; scene fits in cache, so "
+            "not HBM); FMA contraction is forbidden by the parity contract, hence the 39.3 TFLOP/s peak (one "
+            "flop per lane per issue). `achieved`/`frac` count executed flops: the reference's arithmetic "
+            "minus products with exact zeros of axis-aligned inverses and minus ray-sphere pairs the "
+            "bounding test dismisses, plus that test; `*_algorithmic` count the reference's 54 flops per "
+            "ray-sphere and 11 per ray-plane test whether executed or not",
+        }
+        if pmc:
+            # the flop model against the hardware's own count of f64 instructions (same workload, PMC pass)
+            lanes = pmc["active_lanes_per_valu_inst"]
+            wave = pmc["f64_add_wave_insts"] + pmc["f64_mul_wave_insts"] + pmc["f64_fma_wave_insts"]
+            lane_ops = wave * lanes
+            lane_flops = (wave + pmc["f64_fma_wave_insts"]) * lanes
+            roofline["counter_check"] = {
+                "f64_lane_ops_per_launch": lane_ops,
+                "f64_lane_flops_per_launch_fma_as_2": lane_flops,
+                "model_over_lane_flops": local_executed / lane_flops if lane_flops else None,
+                "issue_frac_from_counters": lane_ops / sec / 1e12 / PEAK_FP64_NO_FMA_TFLOPS,
+                "active_lanes_per_valu_inst": lanes,
+                "valu_busy": pmc["valu_busy"],
+                "f64_share_of_valu_insts": wave / pmc["valu_wave_insts"],
+                "source": pmc["source"],
+                "note": "f64 add+mul+fma wave-instructions x average active lanes (fused operations occur "
+                "only in the bounding tests and inside division/sqrt expansions); counted once per "
+                "instruction for the issue fraction, FMA twice for the flop comparison. The counters also "
+                "see division, sqrt and pow expansions, which the model prices at one flop each",
+            }
         out = {
             "metric": "rays/sec (primary+secondary) at 3840x2160 depth 5" if args.workload == "c3"
             else f"rays/sec (primary+secondary), workload {args.workload}",
@@ -352,32 +414,11 @@ def main():
                 if args.accel else "every shape against every ray (calc.zig:204-209)",
                 "render_kernel_ms_max_over_ranks": kernel_ms_max,
             },
-            "roofline": {
-                "bound": "fp64-valu",
-                "achieved": achieved,
-                "peak": PEAK_FP64_NO_FMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_NO_FMA_TFLOPS,
-                "traffic": pmc_traffic(args.workload, world_size),
-                "kernel": "render_kernel",
-                "kernel_ms": kernel_ms,
-                "algorithmic_flops_per_launch": local_flops,
-                "executed_flops_per_launch": local_executed,
-                "achieved_executed": local_executed / (kernel_ms * 1e-3) / 1e12,
-                "frac_executed": local_executed / (kernel_ms * 1e-3) / 1e12 / PEAK_FP64_NO_FMA_TFLOPS,
-                "peak_with_fma": PEAK_FP64_FMA_TFLOPS,
-                "frac_of_fma_peak": achieved / PEAK_FP64_FMA_TFLOPS,
-                "note": "compute-bound FP64 vector path (no dense contraction, so not MFMA; scene fits in cache, "
-                "so not HBM); FMA contraction is forbidden by the parity contract, hence the 39.3 TFLOP/s peak. "
-                "`achieved` counts the reference's algorithmic flops (54 per ray-sphere, 11 per ray-plane test); "
-                "`achieved_executed` counts what the kernel executes after skipping products with exact zeros of "
-                "axis-aligned inverses and the ray-sphere pairs its bounding-sphere test dismisses, so `frac` can "
-                "exceed `frac_executed` (and 1.0 on scenes of many such shapes)",
-            },
+            "roofline": roofline,
         }
         if args.accel:
             # the flop model describes the list walk, not the hierarchy's traversal
-            for k in ("achieved", "frac", "achieved_executed", "frac_executed", "frac_of_fma_peak"):
+            for k in ("achieved", "frac", "achieved_algorithmic", "frac_algorithmic", "frac_of_fma_peak"):
                 out["roofline"][k] = None
             out["roofline"]["note"] = "--accel: the hierarchy skips most of the reference's ray-shape tests; no roofline is claimed for it"
         if world_size > 1:
