@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 #   per plane hit        +2  (shape.zig:65 negate, divide)
 #   per shaded hit      190  (prepareComputations 75, shadow ray set-up 12, lighting 60 incl. pow,
 #                             child set-up / Schlick / unwinding 43; patterns add ~40 where present)
-FLOPS_SPHERE_TEST, FLOPS_SPHERE_HIT, FLOPS_PLANE_TEST, FLOPS_PLANE_HIT, FLOPS_SHADED_HIT = 54, 6, 11, 2, 190
+FLOPS_SPHERE_HIT, FLOPS_PLANE_HIT, FLOPS_SHADED_HIT = 6, 2, 190  # per-test prices come from rtc_sweep_group_info
 PEAK_FP64_NO_FMA_TFLOPS = 39.3  # 256 CU x 64 lanes x 2.4 GHz, one flop per lane-op (FMA forbidden for parity)
 PEAK_FP64_FMA_TFLOPS = 78.6
 
@@ -45,34 +45,42 @@ WORKLOADS = {
 }
 
 
-def algorithmic_flops(st):
+def algorithmic_flops(st, groups, table):
+    """The reference's own arithmetic: every (ray, shape) pair at the full price of its kind
+    (rtc_sweep_group_info: flops_reference), plus the roots of the pairs that produce t values,
+    plus the shading of every hit."""
     rays = st["radiance_rays"] + st["shadow_rays"]
-    n_s = st["sphere_tests"] // max(rays, 1)
-    n_p = st["plane_tests"] // max(rays, 1)
+    per_ray = sum(n * g["flops_reference"] for n, g in zip(groups, table))
     return (
-        rays * (FLOPS_SPHERE_TEST * n_s + FLOPS_PLANE_TEST * n_p)
+        rays * per_ray
         + FLOPS_SPHERE_HIT * st["sphere_hits"]
         + FLOPS_PLANE_HIT * st["plane_hits"]
         + FLOPS_SHADED_HIT * st["shaded_hits"]
     )
 
 
-def executed_flops(st, groups):
-    """Flops the sweep actually executes: shapes whose inverse has exact zeros off the diagonal
-    skip the products with those zeros (values unchanged): 30 instead of 54 per ray-sphere test,
-    3 instead of 11 per ray-plane test; every ray-sphere pair first pays 17 flops for the
-    bounding-sphere test (5 more per sweep), and the pairs it dismisses pay nothing else (the
-    dismissed pairs are taken as spread evenly over the two sphere groups); a plane that a shadow
-    ray's origin shares a side of with the light costs its origin row only (2 of 3, or 6 of 11
-    flops; taken as spread evenly over the two plane groups).  Root filters and bookkeeping
-    compares are not counted."""
+def executed_flops(st, groups, table):
+    """Flops the sweep actually executes, group by group (rtc_sweep_group_info: flops_executed):
+    groups whose inverses have exact zeros skip the products with those zeros (values unchanged):
+    30 instead of 54 per ray-sphere test, 3 instead of 11 per ray-plane test; every ray-sphere
+    pair first pays 17 flops for the bounding-sphere test (5 more per sweep), and the pairs it
+    dismisses pay nothing else (the dismissed pairs are taken as spread evenly over the sphere
+    groups); a plane that a shadow ray's origin shares a side of with the light costs its origin
+    row only (2 of 3, or 6 of 11 flops; taken as spread evenly over the plane groups).  Root
+    filters and bookkeeping compares are not counted."""
     rays = st["radiance_rays"] + st["shadow_rays"]
-    s_axis, s_gen, p_axis, p_gen = groups
-    n_s = s_axis + s_gen
     kept = 1.0 - st["sphere_bound_skips"] / max(st["sphere_tests"], 1)
     side = st["plane_side_skips"] / max(st["plane_tests"], 1)
+    per_ray = 5.0
+    for n, g in zip(groups, table):
+        if g["geo"] == 0:  # RTC_GEO_SPHERE
+            per_ray += n * (17 + kept * g["flops_executed"])
+        elif g["geo"] == 1:  # RTC_GEO_PLANE: the direction row is 1 of 3, or 5 of 11 flops
+            per_ray += n * (g["flops_executed"] - side * (1 if g["axis_aligned"] else 5))
+        else:
+            per_ray += n * g["flops_executed"]
     return (
-        rays * (5 + 17 * n_s + kept * (30 * s_axis + 54 * s_gen) + (3 - side) * p_axis + (11 - 5 * side) * p_gen)
+        rays * per_ray
         + FLOPS_SPHERE_HIT * st["sphere_hits"]
         + FLOPS_PLANE_HIT * st["plane_hits"]
         + FLOPS_SHADED_HIT * st["shaded_hits"]
@@ -273,8 +281,9 @@ def main():
     names = ["radiance_rays", "shadow_rays", "sphere_tests", "plane_tests", "sphere_hits", "plane_hits", "shaded_hits",
              "sphere_bound_skips", "plane_side_skips"]
     total = dict(zip(names, (int(v) for v in counts.tolist())))
-    local_flops = algorithmic_flops(st.as_dict())
-    local_executed = executed_flops(st.as_dict(), scene.group_counts())
+    group_table = native.sweep_group_table()
+    local_flops = algorithmic_flops(st.as_dict(), scene.group_counts(), group_table)
+    local_executed = executed_flops(st.as_dict(), scene.group_counts(), group_table)
 
     for _ in range(args.warmup):
         step()

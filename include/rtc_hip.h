@@ -41,6 +41,11 @@ extern "C" {
 /* Shape.geo, shape.zig:76-79 */
 #define RTC_GEO_SPHERE 0
 #define RTC_GEO_PLANE 1
+/* Extension beyond the reference, which stops at sphere and plane: the axis-aligned cube
+ * [-1, 1]^3 of the book's next chapter, added through the same hook (a new member of the union, a
+ * localIntersect / localNormalAt pair).  A Zig caller only passes it after adding the member to
+ * its own Shape.geo. */
+#define RTC_GEO_CUBE 2
 /* Pattern.pattern, pattern.zig:67-73 */
 #define RTC_PATTERN_POINT 0
 #define RTC_PATTERN_STRIPE 1
@@ -123,6 +128,8 @@ typedef struct RtcStats {
     double kernel_ms;
     uint64_t sphere_bound_skips;
     uint64_t plane_side_skips;
+    uint64_t cube_tests; /* (ray, cube) pairs and those that produced t values (extension, RTC_GEO_CUBE) */
+    uint64_t cube_hits;
 } RtcStats;
 
 /* Opaque handle of an uploaded world (World, world.zig:15-28). */
@@ -159,13 +166,26 @@ int rtc_scene_destroy(RtcScene* scene);
 #define RTC_ACCEL_BVH 1
 int rtc_scene_set_acceleration(RtcScene* scene, int32_t mode);
 
-/* How many shapes of the scene fall in each group of the sweep table: out[0] spheres whose
- * inverse transform is diagonal (3x3 part), out[1] other spheres, out[2] planes whose inverse
- * has row 1 = (0, m, 0, t), out[3] other planes.  The groups with exact zero entries skip the
- * products with those zeros (the values are unchanged), so they execute fewer flops than the
- * reference's 54 per ray-sphere and 11 per ray-plane test; a roofline that wants executed
- * rather than algorithmic flops needs these counts. */
-int rtc_scene_group_counts(const RtcScene* scene, uint64_t out_counts[4]);
+/* The sweep table is grouped by kind of test; each group is swept by a loop specialised for it.
+ * rtc_sweep_group_info describes group `group` (0 <= group < RTC_SWEEP_GROUPS): the Shape.geo value
+ * it serves, whether it is the variant for inverses with exact zeros (a sphere whose inverse's 3x3
+ * part is diagonal; a plane whose inverse has row 1 = (0, m, 0, t)) whose products with those zeros
+ * are not evaluated (the values are unchanged), and the flops of one (ray, shape) test: as the
+ * reference evaluates it, as the group's loop executes it, and extra when the test yields t values.
+ * rtc_scene_group_counts tells how many shapes of a scene fall in each group.  A roofline that
+ * wants executed rather than algorithmic flops needs both. */
+#define RTC_SWEEP_GROUPS 5
+typedef struct RtcSweepGroupInfo {
+    int32_t geo;
+    int32_t axis_aligned;
+    int32_t two_roots;
+    int32_t flops_reference;
+    int32_t flops_executed;
+    int32_t flops_roots;
+    char name[40];
+} RtcSweepGroupInfo;
+int rtc_sweep_group_info(uint32_t group, RtcSweepGroupInfo* out_info);
+int rtc_scene_group_counts(const RtcScene* scene, uint64_t out_counts[RTC_SWEEP_GROUPS]);
 
 /* Camera.render (camera.zig:74-89): fill out_rgb (host memory, hsize*vsize*3 doubles,
  * pixel (x,y) at index (y*hsize + x)*3 as canvas.zig:25, channels red,green,blue as

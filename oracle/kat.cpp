@@ -697,6 +697,65 @@ int main() {
         CHECK(approx(std::pow(0.3, 2.25), zigmath::pow(0.3, 2.25), 1e-15));
     });
 
+    // ------------------------------------------------------------ extension: the cube (not in the reference)
+    // The reference has no cube; these are the scenarios of the book's Ch. 12 ("Cubes"), the chapter after the
+    // last one the reference implements, with the book's inputs and answers, at the reference's tolerances.
+    run("extension (book Ch. 12, no reference counterpart): a ray intersects a cube", [] {
+        const double cases[7][8] = {{5, 0.5, 0, -1, 0, 0, 4, 6},  {-5, 0.5, 0, 1, 0, 0, 4, 6}, {0.5, 5, 0, 0, -1, 0, 4, 6},
+                                    {0.5, -5, 0, 0, 1, 0, 4, 6},  {0.5, 0, 5, 0, 0, -1, 4, 6}, {0.5, 0, -5, 0, 0, 1, 4, 6},
+                                    {0, 0.5, 0, 0, 0, 1, -1, 1}};
+        for (const auto& c : cases) {
+            double ts[2] = {0, 0};
+            const Ray r{initPoint(c[0], c[1], c[2]), initVector(c[3], c[4], c[5])};
+            CHECK(cubeLocalIntersect(r, ts) == 2);
+            CHECK_EPS(c[6], ts[0]);
+            CHECK_EPS(c[7], ts[1]);
+        }
+    });
+    run("extension (book Ch. 12, no reference counterpart): a ray misses a cube", [] {
+        const double cases[6][6] = {{-2, 0, 0, 0.2673, 0.5345, 0.8018}, {0, -2, 0, 0.8018, 0.2673, 0.5345},
+                                    {0, 0, -2, 0.5345, 0.8018, 0.2673}, {2, 0, 2, 0, 0, -1},
+                                    {0, 2, 2, 0, -1, 0},                {2, 2, 0, -1, 0, 0}};
+        for (const auto& c : cases) {
+            double ts[2];
+            CHECK(cubeLocalIntersect(Ray{initPoint(c[0], c[1], c[2]), initVector(c[3], c[4], c[5])}, ts) == 0);
+        }
+    });
+    run("extension (book Ch. 12, no reference counterpart): the normal on the surface of a cube", [] {
+        const double cases[8][6] = {{1, 0.5, -0.8, 1, 0, 0},  {-1, -0.2, 0.9, -1, 0, 0}, {-0.4, 1, -0.1, 0, 1, 0},
+                                    {0.3, -1, -0.7, 0, -1, 0}, {-0.6, 0.3, 1, 0, 0, 1},   {0.4, 0.4, -1, 0, 0, -1},
+                                    {1, 1, 1, 1, 0, 0},        {-1, -1, -1, -1, 0, 0}};
+        for (const auto& c : cases)
+            CHECK_VEC(initVector(c[3], c[4], c[5]), localNormalAt(GEO_CUBE, initPoint(c[0], c[1], c[2])));
+    });
+    run("extension: a transformed cube through Shape.intersect / Shape.normalAt, both integrators", [] {
+        World w;
+        w.light = PointLight{initPoint(-10, 10, -10), Color{1, 1, 1}};
+        Shape cube;
+        cube.geo = GEO_CUBE;
+        cube.transform = Mat4::identity().scale(1, 2, 3).translate(0, 0, 4);
+        cube.material.transparency = 0.5;
+        cube.material.reflective = 0.3;
+        cube.material.refractive_index = 1.5;
+        w.objects.push_back(cube);
+        Shape floor = planeShape();
+        floor.transform = Mat4::identity().translate(0, -2.5, 0);
+        w.objects.push_back(floor);
+        double ts[2] = {0, 0};
+        CHECK(intersectShape(cube, Ray{initPoint(0, 0, -5), initVector(0, 0, 1)}, ts) == 2);
+        CHECK_EPS(6.0, ts[0]);
+        CHECK_EPS(12.0, ts[1]);
+        CHECK_VEC(initVector(0, 0, -1), normalAt(cube, initPoint(0.2, 0.3, 1)));
+        CHECK_VEC(initVector(0, 1, 0), normalAt(cube, initPoint(0.2, 2, 3)));
+        w.prepare();
+        for (double dx = -0.4; dx < 0.5; dx += 0.1)
+            for (double oz : {-5.0, 4.0}) {  // from outside and from inside the cube
+                const Ray r{initPoint(0.1, 0.2, oz), initVector(dx, -0.3, 1).normalize()};
+                const Color a = worldColorAt(w, r, 5, LITERAL), b = worldColorAt(w, r, 5, STREAMING);
+                CHECK(a.red == b.red && a.green == b.green && a.blue == b.blue);
+            }
+    });
+
     std::printf("%s: %d failed\n", g_fail ? "KAT FAILED" : "KAT PASSED", g_fail);
     return g_fail ? 1 : 0;
 }

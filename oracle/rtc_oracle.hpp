@@ -214,7 +214,9 @@ struct Mat4 {
 
 // ---------------------------------------------------------------- pattern/material/shape/light/world
 enum PatternKind { PAT_POINT = 0, PAT_STRIPE = 1, PAT_GRADIENT = 2, PAT_RING = 3, PAT_CHECKERS = 4 };
-enum GeoKind { GEO_SPHERE = 0, GEO_PLANE = 1 };
+// GEO_CUBE is NOT in the reference (shape.zig:76-79 has sphere and plane): it is the next primitive
+// the `geo` union is the hook for, written the way the reference writes its two (see cubeLocalIntersect).
+enum GeoKind { GEO_SPHERE = 0, GEO_PLANE = 1, GEO_CUBE = 2 };
 
 struct Pattern {  // pattern.zig:64-75
     int kind = PAT_POINT;
@@ -306,6 +308,7 @@ struct Intersections {  // ray.zig:62-93
 struct Stats {
     uint64_t radiance_rays = 0, shadow_rays = 0, sphere_tests = 0, plane_tests = 0;
     uint64_t sphere_hits = 0, plane_hits = 0, shaded_hits = 0;
+    uint64_t cube_tests = 0, cube_hits = 0;
 };
 
 struct World {  // world.zig:15-28
@@ -529,8 +532,57 @@ inline int planeLocalIntersect(const Ray& ray, double out_t[2]) {
     out_t[0] = -ray.origin.y / ray.direction.y;
     return 1;
 }
+// ---- extension beyond the reference: the axis-aligned cube [-1, 1]^3 --------------------------------
+// The reference stops at Ch. 11 and has no cube; `Shape.geo` (shape.zig:76-79) is where the book's next
+// primitive would be added, with a localIntersect / localNormalAt pair like the two existing ones
+// (shape.zig:17-70).  This restates the book's Ch. 12 algorithm in the reference's idiom: f64, the
+// parallel test against std.math.epsilon(f64) as Plane.localIntersect does (shape.zig:62), std.math.max /
+// std.math.min as plain comparisons (a > b ? a : b), both t always appended, smaller first.  There is no
+// reference output to compare with: PARITY UNPINNED; the oracle defines the behaviour the device must match.
+inline void cubeCheckAxis(double origin, double direction, double* tmin, double* tmax) {
+    const double tmin_numerator = -1.0 - origin;
+    const double tmax_numerator = 1.0 - origin;
+    double lo, hi;
+    if (std::fabs(direction) >= F64_EPSILON) {
+        lo = tmin_numerator / direction;
+        hi = tmax_numerator / direction;
+    } else {
+        lo = tmin_numerator * std::numeric_limits<double>::infinity();
+        hi = tmax_numerator * std::numeric_limits<double>::infinity();
+    }
+    if (lo > hi) {
+        const double t = lo;
+        lo = hi;
+        hi = t;
+    }
+    *tmin = lo;
+    *tmax = hi;
+}
+inline double max2(double a, double b) { return a > b ? a : b; }  // std.math.max
+inline double min2(double a, double b) { return a < b ? a : b; }  // std.math.min
+inline int cubeLocalIntersect(const Ray& ray, double out_t[2]) {
+    double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+    cubeCheckAxis(ray.origin.x, ray.direction.x, &xtmin, &xtmax);
+    cubeCheckAxis(ray.origin.y, ray.direction.y, &ytmin, &ytmax);
+    cubeCheckAxis(ray.origin.z, ray.direction.z, &ztmin, &ztmax);
+    const double tmin = max2(max2(xtmin, ytmin), ztmin);
+    const double tmax = min2(min2(xtmax, ytmax), ztmax);
+    if (tmin > tmax) return 0;
+    out_t[0] = tmin;
+    out_t[1] = tmax;
+    return 2;
+}
+inline Vec4 cubeLocalNormalAt(const Vec4& p) {
+    const double ax = std::fabs(p.x), ay = std::fabs(p.y), az = std::fabs(p.z);
+    const double maxc = max2(max2(ax, ay), az);
+    if (maxc == ax) return initVector(p.x, 0, 0);
+    if (maxc == ay) return initVector(0, p.y, 0);
+    return initVector(0, 0, p.z);
+}
+
 inline Vec4 localNormalAt(int geo, const Vec4& p) {  // shape.zig:18-21, 49-53
     if (geo == GEO_SPHERE) return p.sub(initPoint(0, 0, 0)).normalize();
+    if (geo == GEO_CUBE) return cubeLocalNormalAt(p);
     return initVector(0, 1, 0);
 }
 // Shape.normalAt, shape.zig:84-97, given the object's inverse
@@ -548,6 +600,7 @@ inline Vec4 normalAt(const Shape& s, const Vec4& world_point) {
 inline int intersectShape(const Shape& s, const Ray& world_ray, double out_t[2]) {
     const Mat4 object_space = s.transform.inverse();
     const Ray local_ray = world_ray.transform(object_space);
+    if (s.geo == GEO_CUBE) return cubeLocalIntersect(local_ray, out_t);
     return s.geo == GEO_SPHERE ? sphereLocalIntersect(local_ray, out_t) : planeLocalIntersect(local_ray, out_t);
 }
 
@@ -631,6 +684,9 @@ inline Intersections intersectWorld(const World& world, const Ray& world_ray) {
         if (object.geo == GEO_SPHERE) {
             world.stats.sphere_tests++;
             if (n) world.stats.sphere_hits++;
+        } else if (object.geo == GEO_CUBE) {
+            world.stats.cube_tests++;
+            if (n) world.stats.cube_hits++;
         } else {
             world.stats.plane_tests++;
             if (n) world.stats.plane_hits++;
@@ -747,10 +803,17 @@ inline SweepResult sweepStreaming(const World& world, const Ray& ray) {
         const Shape& o = world.objects[(size_t)i];
         const Ray local = ray.transform(world.inv[(size_t)i]);
         double ts[2];
-        if (o.geo == GEO_SPHERE) {
-            world.stats.sphere_tests++;
-            if (sphereLocalIntersect(local, ts) == 0) continue;
-            world.stats.sphere_hits++;
+        if (o.geo == GEO_SPHERE || o.geo == GEO_CUBE) {
+            // two t per shape, the smaller first: a convex solid the origin is inside of is an open container
+            if (o.geo == GEO_SPHERE) {
+                world.stats.sphere_tests++;
+                if (sphereLocalIntersect(local, ts) == 0) continue;
+                world.stats.sphere_hits++;
+            } else {
+                world.stats.cube_tests++;
+                if (cubeLocalIntersect(local, ts) == 0) continue;
+                world.stats.cube_hits++;
+            }
             const double t1 = ts[0], t2 = ts[1];
             if (t1 >= 0) {
                 if (r.hit_index < 0 || t1 < r.hit_t) {

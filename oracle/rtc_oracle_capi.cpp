@@ -72,6 +72,8 @@ void fillStats(const orc::Stats& s, RtcStats* out, uint64_t pixels, double ms) {
     out->kernel_ms = ms;
     out->sphere_bound_skips = 0;  // the reference evaluates every pair
     out->plane_side_skips = 0;
+    out->cube_tests = s.cube_tests;
+    out->cube_hits = s.cube_hits;
 }
 
 }  // namespace

@@ -180,10 +180,10 @@ bool valid_stream_and_ptr(const void* p) { return p != nullptr; }
 struct RtcScene {
     int device = 0;
     uint64_t n = 0;
-    uint64_t n_spheres = 0, n_planes = 0;
+    uint64_t n_spheres = 0, n_planes = 0, n_cubes = 0;
     double* d_tab = nullptr;
     int32_t* d_order = nullptr;
-    int32_t group[5] = {0, 0, 0, 0, 0};
+    int32_t group[rtc::kSweepGroups + 1] = {};
     rtc::DevShade* d_shade = nullptr;
     uint32_t* d_counter = nullptr;  // control block: work-queue heads, statistics counters (see rtc_internal.h)
     uint64_t* d_stats = nullptr;
@@ -279,7 +279,7 @@ int check_camera(const RtcCameraDesc* c) {
 
 // Fill stats from the device counters (after the stream has been synchronised).
 int read_stats(RtcScene* s, const uint64_t* d_stats, RtcStats* out, uint64_t pixels, float ms) {
-    uint64_t h[7];
+    uint64_t h[8];
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     out->radiance_rays = h[0];
     out->shadow_rays = h[1];
@@ -290,6 +290,8 @@ int read_stats(RtcScene* s, const uint64_t* d_stats, RtcStats* out, uint64_t pix
     out->shaded_hits = h[4];
     out->sphere_bound_skips = h[5];
     out->plane_side_skips = h[6];
+    out->cube_tests = (h[0] + h[1]) * s->n_cubes;
+    out->cube_hits = h[7];
     out->pixels = pixels;
     out->kernel_ms = ms;
     return RTC_OK;
@@ -904,16 +906,16 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     std::vector<double> inv12(n_shapes * 12);
     std::vector<int> group_of(n_shapes);
     std::vector<rtc::DevShade> shade(n_shapes);
-    uint64_t n_spheres = 0, n_planes = 0;
+    uint64_t n_spheres = 0, n_planes = 0, n_cubes = 0;
     std::unordered_map<uint64_t, std::vector<uint64_t>> buckets;
     for (uint64_t i = 0; i < n_shapes; ++i) {
         const RtcShapeDesc& s = shapes[i];
-        if (s.geo != RTC_GEO_SPHERE && s.geo != RTC_GEO_PLANE) {
+        if (s.geo != RTC_GEO_SPHERE && s.geo != RTC_GEO_PLANE && s.geo != RTC_GEO_CUBE) {
             char buf[96];
             std::snprintf(buf, sizeof buf, "shape %llu: unknown geo %d", (unsigned long long)i, s.geo);
             return fail(RTC_ERR_INVALID_ARGUMENT, buf);
         }
-        (s.geo == RTC_GEO_SPHERE ? n_spheres : n_planes)++;
+        (s.geo == RTC_GEO_SPHERE ? n_spheres : s.geo == RTC_GEO_PLANE ? n_planes : n_cubes)++;
         double full[16];
         if (int rc = invert_affine(s.transform, full, "shape", i)) return rc;
         std::memcpy(&inv12[i * 12], full, 12 * sizeof(double));
@@ -923,7 +925,16 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         const double* f = full;
         const bool row1_axis = f[4] == 0.0 && f[6] == 0.0;
         const bool diagonal = row1_axis && f[1] == 0.0 && f[2] == 0.0 && f[8] == 0.0 && f[9] == 0.0;
-        group_of[i] = s.geo == RTC_GEO_SPHERE ? (diagonal ? 0 : 1) : (row1_axis ? 2 : 3);
+        // the group of the table (rtc::kSweepGroupTable) that serves this geo, the zero-skipping variant if it applies
+        const bool zeros = s.geo == RTC_GEO_SPHERE ? diagonal : row1_axis;
+        group_of[i] = -1;
+        for (int g = 0; g < rtc::kSweepGroups; ++g) {
+            const rtc::SweepGroupInfo& info = rtc::kSweepGroupTable[g];
+            if (info.geo != s.geo || (info.axis_aligned && !zeros)) continue;
+            group_of[i] = g;
+            break;  // the specialised variant of a kind precedes its general one
+        }
+        if (group_of[i] < 0) return fail(RTC_ERR_INVALID_ARGUMENT, "no sweep group serves this shape kind");
         rtc::DevShade& d = shade[i];
         std::memset(&d, 0, sizeof d);
         const RtcMaterialDesc& m = s.material;
@@ -993,10 +1004,10 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     std::vector<double> tab((n_shapes + 2) * kRec, 0.0);
     std::vector<int32_t> order(n_shapes ? n_shapes : 1, 0);
     std::vector<rtc::DevShade> shade_tab(n_shapes);
-    int32_t group[5] = {0, 0, 0, 0, 0};
+    int32_t group[rtc::kSweepGroups + 1] = {};
     {
         size_t pos = 0;
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < rtc::kSweepGroups; ++g) {
             group[g] = (int32_t)pos;
             for (uint64_t i = 0; i < n_shapes; ++i) {
                 if (group_of[i] != g) continue;
@@ -1017,7 +1028,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 ++pos;
             }
         }
-        group[4] = (int32_t)pos;
+        group[rtc::kSweepGroups] = (int32_t)pos;
     }
 
     RtcScene* sc = new (std::nothrow) RtcScene();
@@ -1034,14 +1045,16 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
             sc->costly_everywhere = true;
             continue;
         }
-        // unit sphere under the shape's transform: centre = translation column
+        // unit sphere (or the cube's corners, sqrt(3) from its centre) under the shape's transform:
+        // centre = translation column
         const double* t = s.transform;
-        sc->costly.push_back({{t[3], t[7], t[11]}, largest_stretch(t)});
+        sc->costly.push_back({{t[3], t[7], t[11]}, largest_stretch(t) * (s.geo == RTC_GEO_CUBE ? 1.7320508075688774 : 1.0)});
     }
     sc->sphere_bounds = std::move(bounds);
     sc->n = n_shapes;
     sc->n_spheres = n_spheres;
     sc->n_planes = n_planes;
+    sc->n_cubes = n_cubes;
     for (int i = 0; i < 3; ++i) {
         sc->light_pos[i] = light->position[i];
         sc->light_int[i] = light->intensity[i];
@@ -1115,9 +1128,24 @@ int rtc_scene_set_acceleration(RtcScene* scene, int32_t mode) {
     return RTC_OK;
 }
 
-int rtc_scene_group_counts(const RtcScene* scene, uint64_t out_counts[4]) {
+int rtc_scene_group_counts(const RtcScene* scene, uint64_t out_counts[RTC_SWEEP_GROUPS]) {
     if (!scene || !out_counts) return fail(RTC_ERR_INVALID_ARGUMENT, "NULL pointer");
-    for (int g = 0; g < 4; ++g) out_counts[g] = (uint64_t)(scene->group[g + 1] - scene->group[g]);
+    for (int g = 0; g < rtc::kSweepGroups; ++g) out_counts[g] = (uint64_t)(scene->group[g + 1] - scene->group[g]);
+    return RTC_OK;
+}
+
+int rtc_sweep_group_info(uint32_t group, RtcSweepGroupInfo* out_info) {
+    if (!out_info) return fail(RTC_ERR_INVALID_ARGUMENT, "out_info is NULL");
+    if (group >= (uint32_t)rtc::kSweepGroups) return fail(RTC_ERR_INVALID_ARGUMENT, "group must be < RTC_SWEEP_GROUPS");
+    const rtc::SweepGroupInfo& info = rtc::kSweepGroupTable[group];
+    std::memset(out_info, 0, sizeof *out_info);
+    out_info->geo = info.geo;
+    out_info->axis_aligned = info.axis_aligned;
+    out_info->two_roots = info.two_roots;
+    out_info->flops_reference = info.flops_reference;
+    out_info->flops_executed = info.flops_executed;
+    out_info->flops_roots = info.flops_roots;
+    std::snprintf(out_info->name, sizeof out_info->name, "%s", info.name);
     return RTC_OK;
 }
 

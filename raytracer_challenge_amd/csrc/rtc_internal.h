@@ -28,6 +28,33 @@ constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 64;
 
 constexpr int kRecordDoubles = 24;  // doubles per sweep-table record (see DevWorld)
 
+// The sweep table is grouped by kind of test: one row per group, in table order.  A shape kind
+// (Shape.geo, shape.zig:76-79) owns one or more groups; a group is swept by a loop specialised for
+// it (rtc_kernels.hip: sweep_shape<KIND>), and this table is what the host side consults to place a
+// shape, to report per-group counts and to price a test.  Adding a primitive = a geo value, its
+// rows here, its branch in sweep_shape (local intersect) and in the hit's normal (local normal).
+//   flops_reference  the reference's own arithmetic for one (ray, shape) test: Ray.transform of
+//                    origin and direction plus the local intersect up to the hit/miss decision
+//   flops_executed   what the specialised loop evaluates (products with exact zeros left out)
+//   flops_roots      extra arithmetic when the test produces t values
+constexpr int kSweepGroups = RTC_SWEEP_GROUPS;
+struct SweepGroupInfo {
+    int32_t geo;
+    int32_t axis_aligned;  // the group's inverses have exact zeros where the test multiplies (see rtc_scene_create)
+    int32_t two_roots;     // 1: closed convex solid, two t per hit, can be an open container while the origin is inside
+    int32_t flops_reference, flops_executed, flops_roots;
+    const char* name;
+};
+constexpr SweepGroupInfo kSweepGroupTable[kSweepGroups] = {
+    {RTC_GEO_SPHERE, 1, 1, 54, 30, 6, "sphere, diagonal inverse"},
+    {RTC_GEO_SPHERE, 0, 1, 54, 54, 6, "sphere"},
+    {RTC_GEO_PLANE, 1, 0, 11, 3, 2, "plane, inverse row 1 = (0, m, 0, t)"},
+    {RTC_GEO_PLANE, 0, 0, 11, 11, 2, "plane"},
+    // extension beyond the reference: axis-aligned cube; 33 for the two transforms, 6 numerators,
+    // 6 divisions (the comparisons are not counted, as everywhere); its t values come with the test
+    {RTC_GEO_CUBE, 0, 1, 45, 45, 0, "cube"},
+};
+
 struct DevShade {
     double color[3];
     double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
@@ -76,7 +103,7 @@ struct DevWorld {
     const DevShade* shade;
     const int32_t* order;
     int32_t n;
-    int32_t group[5];
+    int32_t group[kSweepGroups + 1];
     // acceleration (rtc_scene_set_acceleration): nullptr = every sphere is tested (the reference's list walk)
     const BvhNode* bvh;
     int32_t bvh_root;        // child code of the root
@@ -108,7 +135,7 @@ struct DevJob {
     int32_t depth;
     double* out;
     uint32_t* counter;  // control block: the work-queue heads first, zeroed before the launch
-    uint64_t* stats;    // 7 counters (radiance, shadow, sphere hits, plane hits, shaded, sphere skips, plane skips) or nullptr
+    uint64_t* stats;    // 8 counters (radiance, shadow, sphere hits, plane hits, shaded, sphere skips, plane skips, cube hits) or nullptr
 };
 
 // Launchers implemented in rtc_kernels.hip.  grid_blocks == 0 lets the launcher size the

@@ -283,7 +283,7 @@ constexpr double kOnePlus = 1.0 + 0x1p-40;
 // STATS builds only: (ray, shape) pairs whose local intersect produced roots, and pairs the
 // bounding-sphere test dismissed.
 struct SweepCounters {
-    uint32_t sphere_hits, plane_hits, sphere_skips, plane_skips;
+    uint32_t sphere_hits, plane_hits, sphere_skips, plane_skips, cube_hits;
 };
 
 struct ShapeRec {
@@ -333,7 +333,29 @@ struct ContainerSlots {
 // The table holds the shapes in four groups, each in list order, so that each group is
 // swept by a loop specialised for it: no per-shape dispatch, and the zero entries of
 // axis-aligned inverses are never multiplied.
-enum : int { kSphereAxis = 0, kSphereGeneral = 1, kPlaneAxis = 2, kPlaneGeneral = 3 };
+enum : int { kSphereAxis = 0, kSphereGeneral = 1, kPlaneAxis = 2, kPlaneGeneral = 3, kCube = 4 };
+static_assert(kSweepGroupTable[kSphereAxis].geo == RTC_GEO_SPHERE && kSweepGroupTable[kSphereAxis].axis_aligned &&
+                  kSweepGroupTable[kSphereGeneral].geo == RTC_GEO_SPHERE && kSweepGroupTable[kPlaneAxis].geo == RTC_GEO_PLANE &&
+                  kSweepGroupTable[kPlaneAxis].axis_aligned && kSweepGroupTable[kPlaneGeneral].geo == RTC_GEO_PLANE &&
+                  kSweepGroupTable[kCube].geo == RTC_GEO_CUBE && kSweepGroups == 5,
+              "the specialised loops follow the group table");
+
+// std.math.max / std.math.min as the plain comparisons they are (a NaN operand is kept or dropped
+// exactly as the comparison decides, which fmax/fmin would not reproduce)
+__device__ __forceinline__ double max_cmp(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double min_cmp(double a, double b) { return a < b ? a : b; }
+// One slab of the cube [-1, 1]^3 (the book's check_axis, in the reference's idiom: the parallel test
+// against the f64 epsilon as shape.zig:62 does, the swap by comparison)
+__device__ __forceinline__ void cube_axis(double origin, double direction, double& lo, double& hi) {
+    const double n0 = -1.0 - origin, n1 = 1.0 - origin;
+    const bool parallel = !(fabs(direction) >= kF64Eps);
+    const double inf = __builtin_huge_val();
+    const double a = parallel ? n0 * inf : n0 / direction;
+    const double b = parallel ? n1 * inf : n1 / direction;
+    const bool swap = a > b;
+    lo = swap ? b : a;
+    hi = swap ? a : b;
+}
 
 // One shape against one ray.  The reference's list order decides ties (stable sort by t,
 // ray.zig:75-92): among equal t the shape earlier in the list is the hit, and the one later
@@ -414,6 +436,28 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
                 push_t = t1;
             }
         }
+        }
+    } else if (KIND == kCube) {
+        // extension beyond the reference: Ray.transform (ray.zig:31-36), then the three slabs
+        const V3 lo = xform_point(m, o);
+        const V3 ld = xform_dir(m, d);
+        double x0, x1, y0, y1, z0, z1;
+        cube_axis(lo.x, ld.x, x0, x1);
+        cube_axis(lo.y, ld.y, y0, y1);
+        cube_axis(lo.z, ld.z, z0, z1);
+        const double t1 = max_cmp(max_cmp(x0, y0), z0);
+        const double t2 = min_cmp(min_cmp(x1, y1), z1);
+        if (!(t1 > t2)) {
+            if (STATS) ++ctr.cube_hits;
+            const bool in1 = t1 >= 0;
+            const bool in2 = !in1 && t2 >= 0;  // t2 >= t1 never beats t1 under strict <
+            cand = in1 ? t1 : t2;
+            better = (in1 || in2) && (!have || cand < s.t);
+            if (!SHADOW && (in1 || in2) && s.idx >= 0 && cand == s.t)
+                better = (int)rec.order < order_of[s.idx & ~kExitOpenBit];
+            cand_idx = in2 ? (pos | kExitOpenBit) : pos;
+            push = in2;
+            push_t = t1;
         }
     } else {
         // Plane.localIntersect (shape.zig:55-70): only row 1 of the local ray is used
@@ -616,6 +660,7 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     }
     sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
+    sweep_group<kCube, SHADOW, STATS>(tab, order_of, w.group[4], w.group[5], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     if (ACCEL) {
         if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, shadow_margin, s, cs, ctr);
     } else {
@@ -1083,13 +1128,23 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 const V3 eyev = {-rd.x, -rd.y, -rd.z};
                 // Shape.normalAt (shape.zig:84-97)
                 V3 normalv;
-                if (geo == RTC_GEO_SPHERE) {
+                if (geo != RTC_GEO_PLANE) {
                     // gather what the normal needs in one batch (the loads overlap each other)
                     double M[12];
 #pragma unroll
                     for (int q = 0; q < 11; ++q) M[q] = oinv[q];
                     M[11] = oinv[11];
-                    const V3 ln = normalize3(xform_point(M, point));
+                    const V3 lp = xform_point(M, point);
+                    V3 ln;
+                    if (geo == RTC_GEO_SPHERE) {
+                        ln = normalize3(lp);  // shape.zig:18-21
+                    } else {
+                        // extension: the face of the cube the point lies on (largest |coordinate|, x before y before z)
+                        const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
+                        const double maxc = max_cmp(max_cmp(ax, ay), az);
+                        const bool fx = maxc == ax, fy = !fx && maxc == ay;
+                        ln = {fx ? lp.x : 0.0, fy ? lp.y : 0.0, (fx || fy) ? 0.0 : lp.z};
+                    }
                     normalv = normalize3(V3{(M[0] * ln.x + M[4] * ln.y) + M[8] * ln.z,
                                             (M[1] * ln.x + M[5] * ln.y) + M[9] * ln.z,
                                             (M[2] * ln.x + M[6] * ln.y) + M[10] * ln.z});
@@ -1326,8 +1381,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
     if (STATS) {
         // one atomic per counter per wave
-        uint32_t v[7] = {n_radiance, n_shadow, ctr.sphere_hits, ctr.plane_hits, n_shaded, ctr.sphere_skips, ctr.plane_skips};
-        for (int c = 0; c < 7; ++c) {
+        uint32_t v[8] = {n_radiance, n_shadow, ctr.sphere_hits, ctr.plane_hits, n_shaded, ctr.sphere_skips, ctr.plane_skips,
+                         ctr.cube_hits};
+        for (int c = 0; c < 8; ++c) {
             unsigned long long sum = v[c];
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
             if (lane == 0) atomicAdd(&g_stats[c], sum);

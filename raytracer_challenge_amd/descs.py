@@ -16,6 +16,8 @@ RTC_ERR_TOO_LARGE = 7
 
 RTC_GEO_SPHERE = 0
 RTC_GEO_PLANE = 1
+RTC_GEO_CUBE = 2  # extension beyond the reference
+RTC_SWEEP_GROUPS = 5
 
 RTC_PATTERN_POINT = 0
 RTC_PATTERN_STRIPE = 1
@@ -101,6 +103,8 @@ class RtcStats(C.Structure):
         ("kernel_ms", C.c_double),
         ("sphere_bound_skips", C.c_uint64),
         ("plane_side_skips", C.c_uint64),
+        ("cube_tests", C.c_uint64),
+        ("cube_hits", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -117,3 +121,20 @@ class RtcMultiTiming(C.Structure):
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class RtcSweepGroupInfo(C.Structure):
+    _fields_ = [
+        ("geo", C.c_int32),
+        ("axis_aligned", C.c_int32),
+        ("two_roots", C.c_int32),
+        ("flops_reference", C.c_int32),
+        ("flops_executed", C.c_int32),
+        ("flops_roots", C.c_int32),
+        ("name", C.c_char * 40),
+    ]
+
+    def as_dict(self):
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["name"] = d["name"].decode()
+        return d

@@ -207,9 +207,10 @@ class Material:
 
 # ----------------------------------------------------------------------------- shape.zig
 class Shape:
-    """Shape (shape.zig:73-82): geo is 'sphere' (the default) or 'plane'."""
+    """Shape (shape.zig:73-82): geo is 'sphere' (the default) or 'plane'; 'cube' is the library's
+    extension beyond the reference (RTC_GEO_CUBE)."""
 
-    GEOS = {"sphere": D.RTC_GEO_SPHERE, "plane": D.RTC_GEO_PLANE}
+    GEOS = {"sphere": D.RTC_GEO_SPHERE, "plane": D.RTC_GEO_PLANE, "cube": D.RTC_GEO_CUBE}
 
     def __init__(self, geo="sphere", transform=None, material=None):
         if geo not in self.GEOS:

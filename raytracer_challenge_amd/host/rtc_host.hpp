@@ -102,7 +102,7 @@ struct Material {
 };
 
 struct Shape {
-    enum Geo { sphere = RTC_GEO_SPHERE, plane = RTC_GEO_PLANE };
+    enum Geo { sphere = RTC_GEO_SPHERE, plane = RTC_GEO_PLANE, cube = RTC_GEO_CUBE /* extension, not in shape.zig:76-79 */ };
     Geo geo = sphere;
     Mat4 transform = Mat4::identity();
     Material material{};

@@ -130,7 +130,7 @@ inline Scene parseScene(std::istream& in, size_t hsize = 0, size_t vsize = 0) {
                 scene.world.light = {initPoint(number(tok[1]), number(tok[2]), number(tok[3])),
                                      Color::init(number(tok[4]), number(tok[5]), number(tok[6]))};
                 have_light = true;
-            } else if (head == "material" || head == "sphere" || head == "plane") {
+            } else if (head == "material" || head == "sphere" || head == "plane" || head == "cube") {
                 size_t first = 1;
                 std::string name;
                 if (head == "material") {
@@ -186,7 +186,7 @@ inline Scene parseScene(std::istream& in, size_t hsize = 0, size_t vsize = 0) {
                     materials[name] = mat;
                 } else {
                     Shape s;
-                    s.geo = head == "plane" ? Shape::plane : Shape::sphere;
+                    s.geo = head == "plane" ? Shape::plane : head == "cube" ? Shape::cube : Shape::sphere;
                     s.transform = transform;
                     s.material = mat;
                     scene.world.objects.push_back(s);

@@ -46,7 +46,8 @@ def lib():
     L.rtc_scene_create.argtypes = [C.POINTER(D.RtcShapeDesc), u64, C.POINTER(D.RtcLightDesc), C.POINTER(vp)]
     L.rtc_scene_destroy.argtypes = [vp]
     L.rtc_scene_set_acceleration.argtypes = [vp, i32]
-    L.rtc_scene_group_counts.argtypes = [vp, C.POINTER(C.c_uint64 * 4)]
+    L.rtc_scene_group_counts.argtypes = [vp, C.POINTER(C.c_uint64 * D.RTC_SWEEP_GROUPS)]
+    L.rtc_sweep_group_info.argtypes = [u32, C.POINTER(D.RtcSweepGroupInfo)]
     L.rtc_render.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, dp, C.POINTER(D.RtcStats)]
     L.rtc_render_u8.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, C.POINTER(C.c_uint8), C.POINTER(D.RtcStats)]
     L.rtc_render_device.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, u32, u32, vp, vp, C.POINTER(D.RtcStats)]
@@ -85,6 +86,7 @@ EXPORTS = (
     "rtc_scene_destroy",
     "rtc_scene_set_acceleration",
     "rtc_scene_group_counts",
+    "rtc_sweep_group_info",
     "rtc_render",
     "rtc_render_u8",
     "rtc_render_device",
@@ -143,6 +145,16 @@ def arith_probe(a, b):
     return q, s, p
 
 
+def sweep_group_table():
+    """rtc_sweep_group_info for every group: a list of dicts (geo, axis_aligned, two_roots, flops_*, name)."""
+    out = []
+    for g in range(D.RTC_SWEEP_GROUPS):
+        info = D.RtcSweepGroupInfo()
+        check(lib().rtc_sweep_group_info(g, C.byref(info)))
+        out.append(info.as_dict())
+    return out
+
+
 def tile_buffer_doubles(camera_desc, tile_rank, tile_ranks):
     n = C.c_uint64(0)
     check(lib().rtc_tile_buffer_doubles(C.byref(camera_desc), tile_rank, tile_ranks, C.byref(n)))
@@ -199,8 +211,8 @@ class Scene:
         check(lib().rtc_scene_set_acceleration(self._h, int(mode)))
 
     def group_counts(self):
-        """rtc_scene_group_counts: (axis spheres, general spheres, axis planes, general planes)."""
-        out = (C.c_uint64 * 4)()
+        """rtc_scene_group_counts: shapes per sweep group, in the order of sweep_group_table()."""
+        out = (C.c_uint64 * D.RTC_SWEEP_GROUPS)()
         check(lib().rtc_scene_group_counts(self._h, C.byref(out)))
         return tuple(int(v) for v in out)
 

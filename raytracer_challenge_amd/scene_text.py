@@ -7,7 +7,7 @@ The same format is read by the C++ host side (host/scene_text.hpp).
     view <from x y z> <to x y z> <up x y z>       camera.transform = viewTransform (calc.zig:721-738)
     light <x y z> <r g b>
     material <name> key=value ...                  a named material (material.zig:6-18 defaults)
-    sphere|plane [material=<name>] key=value ... [transform=<ops>]
+    sphere|plane|cube [material=<name>] key=value ... [transform=<ops>]
 
 keys    color=r,g,b ambient= diffuse= specular= shininess= reflective= transparency=
         refractive_index= pattern=point|stripe|gradient|ring|checkers pattern_a=r,g,b
@@ -109,7 +109,7 @@ def loads(text, hsize=None, vsize=None):
                     raise SceneTextError("light takes 6 numbers")
                 world.light = PointLight(init_point(*v[:3]), Color(*v[3:]))
                 light_seen = True
-            elif head in ("material", "sphere", "plane"):
+            elif head in ("material", "sphere", "plane", "cube"):
                 if head == "material":
                     name, rest = rest[0], rest[1:]
                 kv = {}

@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_the_c_compiler():
-    names = ["RtcPatternDesc", "RtcMaterialDesc", "RtcShapeDesc", "RtcLightDesc", "RtcCameraDesc", "RtcStats", "RtcMultiTiming"]
+    names = ["RtcPatternDesc", "RtcMaterialDesc", "RtcShapeDesc", "RtcLightDesc", "RtcCameraDesc", "RtcStats", "RtcMultiTiming", "RtcSweepGroupInfo"]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "rtc_hip.h"\nint main(void){' + "".join(
         f'printf("%zu\\n", sizeof({n}));' for n in names) + (
         'printf("%zu %zu %zu\\n", offsetof(RtcShapeDesc, transform), offsetof(RtcShapeDesc, material),'
@@ -39,9 +39,9 @@ def test_struct_layout_matches_the_c_compiler():
         exe = os.path.join(d, "t")
         subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
-    sizes = [int(v) for v in out[:7]]
+    sizes = [int(v) for v in out[:8]]
     assert sizes == [C.sizeof(getattr(D, n)) for n in names]
-    assert [int(v) for v in out[7:]] == [D.RtcShapeDesc.transform.offset, D.RtcShapeDesc.material.offset,
+    assert [int(v) for v in out[8:]] == [D.RtcShapeDesc.transform.offset, D.RtcShapeDesc.material.offset,
                                           D.RtcMaterialDesc.pattern.offset]
 
 

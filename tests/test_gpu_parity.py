@@ -20,7 +20,7 @@ from golden_io import GOLDEN_DIR, NAMES, Fixture
 from raytracer_challenge_amd import (Camera, Canvas, Color, Mat4, Material, Pattern, PointLight, Shape, World,
                                      byte_color_values, canvas_to_ppm, descs as D, init_glass_sphere, init_point,
                                      init_vector, native, scenes, tiles, view_transform)
-from worlds import (grazing_world_and_rays, nested_glass_world, random_world, shadow_grazing_world_and_rays,
+from worlds import (cube_world, grazing_world_and_rays, nested_glass_world, random_world, shadow_grazing_world_and_rays,
                     tie_world)
 
 pytestmark = pytest.mark.gpu
@@ -283,7 +283,7 @@ def test_cpp_scene_loader_and_draw_scene_tool(tmp_path):
     canvas_to_ppm(Canvas(240, 135, O.render(w, c, 5, O.STREAMING)), b)
     assert out.read_text() == b.getvalue()
 
-    w, c = random_world(4)
+    w, c = random_world(4, n_cubes=2)
     c.transform = Mat4.identity()
     scene_file = tmp_path / "random.scene"
     scene_file.write_text(scene_text.dumps(w, c))
@@ -485,6 +485,45 @@ def test_synthetic_scene_small_and_full_shape_count():
     got = c.render(w, 5, st).pixels
     assert_identical(got, O.render(w, c, 5, O.STREAMING, stats=so), "synthetic 10k")
     assert st.radiance_rays == so.radiance_rays and st.sphere_hits == so.sphere_hits
+
+
+# ------------------------------------------------------------------------------- the cube (extension)
+def test_cubes_against_the_oracle():
+    """RTC_GEO_CUBE, the primitive added through the shape-kind table beyond the reference's sphere and
+    plane (parity unpinned against Zig: the reference has no cube; the oracle restates the book's
+    algorithm in the reference's idiom and the device must match it value for value): glass cubes
+    nested with spheres, coincident cubes and faces, the camera inside a cube, random sheared cubes,
+    with and without the hierarchy over the spheres, statistics included."""
+    w, c = cube_world()
+    st, so = D.RtcStats(), D.RtcStats()
+    assert_identical(c.render(w, 5, st).pixels, O.render(w, c, 5, O.LITERAL, stats=so), "cube world")
+    for k in ("radiance_rays", "shadow_rays", "cube_tests", "cube_hits", "sphere_hits", "plane_hits", "shaded_hits"):
+        assert getattr(st, k) == getattr(so, k), k
+    assert st.cube_hits > 0
+    assert_identical(_accel_canvas(w, c), O.render(w, c, 5, O.STREAMING), "cube world, hierarchy")
+    for seed in range(4):
+        w, c = random_world(100 + seed, n_spheres=4, n_planes=2, n_cubes=5)
+        assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), f"random cubes {seed}")
+    w, c = random_world(200, n_spheres=30, n_planes=2, n_cubes=12)  # beyond the LDS tables
+    assert_identical(c.render(w, 6).pixels, O.render(w, c, 6, O.LITERAL), "44 shapes with cubes")
+    assert_identical(_accel_canvas(w, c, 6), O.render(w, c, 6, O.STREAMING), "44 shapes with cubes, hierarchy")
+    w, c = random_world(201, n_spheres=0, n_planes=0, n_cubes=7)
+    assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), "cubes only")
+    # rays along the axes (a direction component of exactly zero: the infinite-slab branch) from inside and outside
+    w = World()
+    w.light = PointLight(init_point(-3, 5, -4), Color(1, 1, 1))
+    w.objects.append(Shape("cube", Mat4.identity(), Material(transparency=0.7, reflective=0.2, refractive_index=1.5)))
+    w.objects.append(Shape("cube", Mat4.identity().scale(0.3, 0.3, 0.3).translate(0.2, 0.1, 3)))
+    rays = []
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            for o in ((0.3, -0.2, 0.4), (0.3, -0.2, -5.0), (5.0, 0.2, 0.1), (0.5, 6.0, 0.5), (2.0, 2.0, 2.0)):
+                d = [0.0, 0.0, 0.0]
+                d[axis] = sign
+                rays.append(list(o) + d)
+    rays = np.array(rays)
+    with scene_of(w) as sc:
+        assert_identical(sc.color_at(rays, 5), O.color_at(w, rays, 5, O.LITERAL), "axis-parallel rays")
 
 
 # ------------------------------------------------------------------------------- hierarchy over the spheres

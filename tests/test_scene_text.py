@@ -28,7 +28,7 @@ def test_shipped_draw_world_scene_equals_the_builder():
 
 @pytest.mark.parametrize("seed", range(3))
 def test_dumps_loads_round_trip(seed):
-    w, c = random_world(seed)
+    w, c = random_world(seed, n_cubes=seed)  # cubes: the library's extension beyond the reference's kinds
     # random_world's camera has a view transform; serialise the world with an identity camera
     c.transform = type(c.transform).identity()
     text = scene_text.dumps(w, c)
