@@ -551,10 +551,18 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
     if (begin >= end) return;
     ShapeRec A = load_rec(tab, begin);
     for (int i = begin; i < end; i += 2) {
+#ifdef RTC_LDS_SWEEP
+        asm volatile("" ::"v"(A.order) : "memory");
+#else
         asm volatile("" ::"s"(A.order) : "memory");
+#endif
         const ShapeRec B = load_rec(tab, i + 1);
         sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, dd, side_scale, shadow_margin, s, cs, ctr);
+#ifdef RTC_LDS_SWEEP
+        asm volatile("" ::"v"(B.order) : "memory");
+#else
         asm volatile("" ::"s"(B.order) : "memory");
+#endif
         A = load_rec(tab, i + 2);
         if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     }
@@ -706,7 +714,6 @@ __device__ __forceinline__ V3 pattern_color(const DevShade& sh, const double* __
 //   acc      surface colour, then surface + reflected term (calc.zig:466,468)
 //   meta     flags, the lane tracing an outsourced subtree, and the table position of the hit
 //            shape (its material gives the factor of the reflected child, calc.zig:958)
-//   transp   material.transparency (scales the refracted child, calc.zig:852)
 //   R        Schlick reflectance when flags & kSchlick (calc.zig:464-466)
 //   ray      the refracted ray, parked while the reflected subtree is traced
 // flags: kHasRefract — a refracted child exists; kWaitRefract — the reflected term is already
@@ -751,12 +758,20 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
 // and its material/pattern record) in LDS, copied once per workgroup: a gather then costs an
 // LDS access instead of a chain of dependent trips to the L2, which four waves per SIMD
 // cannot hide.  Larger worlds spend their time in the sweeps and gather from global memory.
+#ifdef RTC_LDS_SWEEP
+// developer experiment: the whole sweep record in LDS, read with wave-uniform LDS addresses (a
+// broadcast into vector registers) instead of scalar loads into scalar registers
+constexpr int kLdsShapes = 16;
+constexpr int kHotMatDoubles = kRecDoubles;
+#else
 constexpr int kLdsShapes = 32;
+constexpr int kHotMatDoubles = 12;
+#endif
 template <bool ON>
 struct HotTables {};
 template <>
 struct HotTables<true> {
-    double mat[kLdsShapes][12];
+    double mat[kLdsShapes + (kHotMatDoubles == 12 ? 0 : 2)][kHotMatDoubles];
     DevShade shade[kLdsShapes];
 };
 static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
@@ -811,7 +826,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     const int tid = (int)threadIdx.x;
     if constexpr (LDS) {
         const int n = wc.n;
-        for (int k = (int)threadIdx.x; k < n * 12; k += kBlock) hot.mat[k / 12][k % 12] = g_tab[(k / 12) * kRecDoubles + k % 12];
+        constexpr int kW = kHotMatDoubles;
+        const int rows = kW == 12 ? n : n + 2;  // with whole records: the two padding records as well
+        for (int k = (int)threadIdx.x; k < rows * kW; k += kBlock) hot.mat[k / kW][k % kW] = g_tab[(k / kW) * kRecDoubles + k % kW];
         const double* __restrict__ src = reinterpret_cast<const double*>(g_shade);
         double* dst = reinterpret_cast<double*>(hot.shade);
         for (int k = (int)threadIdx.x; k < n * (int)(sizeof(DevShade) / 8); k += kBlock) dst[k] = src[k];
@@ -829,6 +846,10 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
         else
             return g_tab + (size_t)i * kRecDoubles;
     };
+    const double* sweep_tab = g_tab;
+#ifdef RTC_LDS_SWEEP
+    if constexpr (LDS) sweep_tab = &hot.mat[0][0];
+#endif
     const int lane = (int)(threadIdx.x & 63);
     DevWorld w = wc;
     w.tab = g_tab;
@@ -839,9 +860,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     double f_acc[kDeep][3];
     int f_meta[kDeep];
     double f_ray[MAXD][6];
-    double f_transp[MAXD], f_R[MAXD];
+    double f_R[MAXD];
 #pragma unroll
-    for (int f = 0; f < MAXD; ++f) f_transp[f] = f_R[f] = 0.0;  // read (and not used) for frames that never set them
+    for (int f = 0; f < MAXD; ++f) f_R[f] = 0.0;  // read (and not used) for frames that never set it
     auto frame_meta = [&](int f) -> int { return f < kLdsFrames ? frames.meta[f][tid] : f_meta[f - kLdsFrames]; };
     auto set_frame_meta = [&](int f, int v) {
         if (f < kLdsFrames)
@@ -1042,9 +1063,10 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             if (got) {
                 // refracted child returned: color.scale(transparency) [.scale(1 - reflectance)]
                 const int f = sp - 1;
-                const double kt = f_transp[f];
+                const int fm = frame_meta(f);
+                const double kt = shade_of(fm >> kMetaShapeShift).transparency;
                 V3 c = {kt * hx, kt * hy, kt * hz};
-                if (frame_meta(f) & kSchlick) {
+                if (fm & kSchlick) {
                     const double T = 1.0 - f_R[f];
                     c = {T * c.x, T * c.y, T * c.z};
                 }
@@ -1111,7 +1133,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
             const int remaining = ((aux >> kAuxRemShift) & 63) - sp;
             Sweep hit;
-            sweep_world<false, STATS, ACCEL>(g_tab, g_order, w, ro, rd, hit, containers, ctr);
+            sweep_world<false, STATS, ACCEL>(sweep_tab, g_order, w, ro, rd, hit, containers, ctr);
             RTC_STAMP(pc_sweep1);
 
             have_ret = true;
@@ -1172,7 +1194,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 Sweep sh_hit;
                 sh_hit.t = distance;
                 RTC_STAMP(pc_prep);
-                sweep_world<true, STATS, ACCEL>(g_tab, g_order, w, over_point, lightv, sh_hit, containers, ctr);
+                sweep_world<true, STATS, ACCEL>(sweep_tab, g_order, w, over_point, lightv, sh_hit, containers, ctr);
                 RTC_STAMP(pc_sweep2);
                 const bool in_shadow = sh_hit.idx >= 0;
 
@@ -1270,7 +1292,6 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     // opaque surface) are the colour so far and the meta word
                     set_frame_acc(sp, surface);
                     if (flags & kSchlick) f_R[sp] = R;
-                    if (has_refract) f_transp[sp] = m_transparency;
                     if (has_reflect) {
                         if (has_refract) {
                             f_ray[sp][0] = under_point.x;
@@ -1307,9 +1328,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
             bool settled = false;  // the lane descended into a child or waits for a helper
             // One pass over the levels from the deepest to the root instead of a loop over the
             // lane's own frames: a lane pops level L when that is its top frame, so every lane is
-            // served whatever its depth, the level is a compile-time constant (LDS or private
-            // memory is decided statically, addresses are fixed) and the frames of different
-            // levels can be fetched independently of the running colour.
+            // served whatever its depth, and the level is a compile-time constant (LDS or private
+            // memory is decided statically, addresses are fixed).
 #pragma unroll
             for (int L = MAXD - 1; L >= 0; --L) {
                 if (!settled && sp == L + 1) {
@@ -1320,8 +1340,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                     // waiting for it, the refracted one (color.scale(transparency), then
                     // .scale(1 - reflectance): calc.zig:852,466): one factor or two, then the sum.
                     const bool refracted_back = (flags & kWaitRefract) != 0;
-                    const double k_reflect = shade_of(flags >> kMetaShapeShift).reflective;
-                    const double k_child = refracted_back ? f_transp[L] : k_reflect;
+                    const DevShade& fs = shade_of(flags >> kMetaShapeShift);
+                    const double k_child = refracted_back ? fs.transparency : fs.reflective;
                     V3 c = {k_child * ret.x, k_child * ret.y, k_child * ret.z};
                     if (flags & kSchlick) {
                         const double fR = f_R[L];
