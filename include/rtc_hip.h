@@ -337,6 +337,18 @@ int rtc_render_multi(RtcMulti* multi, const RtcCameraDesc* camera, int32_t depth
 int rtc_render_multi_u8(RtcMulti* multi, const RtcCameraDesc* camera, int32_t depth, int32_t mode,
                         uint8_t* out_rgb8, RtcStats* stats, RtcMultiTiming* timing);
 
+/* For callers that run one PROCESS per GPU (an MPI- or torchrun-style launch) and want the
+ * peer-store assembly of rtc_render_device_to_canvas: rank 0 creates the canvas and a handle
+ * (hipMalloc + hipIpcGetMemHandle), sends the RTC_IPC_HANDLE_BYTES bytes to the other ranks by
+ * whatever channel it has, each of which maps the canvas into its own address space with
+ * rtc_ipc_canvas_open (hipIpcOpenMemHandle) and renders its tiles straight into it.  The caller
+ * synchronises the ranks (a barrier after the launches) before rank 0 reads the canvas.
+ * rtc_ipc_canvas_close frees (owner) or unmaps (others).  No counterpart in the reference. */
+#define RTC_IPC_HANDLE_BYTES 64
+int rtc_ipc_canvas_create(uint64_t bytes, void** out_d_canvas, uint8_t out_handle[RTC_IPC_HANDLE_BYTES]);
+int rtc_ipc_canvas_open(const uint8_t handle[RTC_IPC_HANDLE_BYTES], void** out_d_canvas);
+int rtc_ipc_canvas_close(void* d_canvas, int32_t is_owner);
+
 /* ---- diagnostics (used by the parity tests) ------------------------------ */
 
 /* Mat4.inverse (matrix.zig:286-300) and Mat4.determinant (matrix.zig:272-280) exactly as

@@ -478,6 +478,45 @@ static int finish_frame(RtcMulti* m, RtcMultiTiming* timing, std::chrono::steady
     return RTC_OK;
 }
 
+// ---- one process per GPU: rank 0's canvas mapped into the other ranks' address spaces ----------
+int rtc_ipc_canvas_create(uint64_t bytes, void** out_d_canvas, uint8_t out_handle[RTC_IPC_HANDLE_BYTES]) {
+    static_assert(sizeof(hipIpcMemHandle_t) <= RTC_IPC_HANDLE_BYTES, "handle fits the caller's buffer");
+    if (!out_d_canvas || !out_handle || bytes == 0) return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "NULL pointer or zero size");
+    *out_d_canvas = nullptr;
+    void* p = nullptr;
+    MULTI_HIP(hipMalloc(&p, bytes));
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        return rtc::set_hip_error("hipIpcGetMemHandle", e);
+    }
+    std::memset(out_handle, 0, RTC_IPC_HANDLE_BYTES);
+    std::memcpy(out_handle, &h, sizeof h);
+    *out_d_canvas = p;
+    return RTC_OK;
+}
+
+int rtc_ipc_canvas_open(const uint8_t handle[RTC_IPC_HANDLE_BYTES], void** out_d_canvas) {
+    if (!handle || !out_d_canvas) return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "NULL pointer");
+    *out_d_canvas = nullptr;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof h);
+    void* p = nullptr;
+    MULTI_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    *out_d_canvas = p;
+    return RTC_OK;
+}
+
+int rtc_ipc_canvas_close(void* d_canvas, int32_t is_owner) {
+    if (!d_canvas) return RTC_OK;
+    if (is_owner)
+        MULTI_HIP(hipFree(d_canvas));
+    else
+        MULTI_HIP(hipIpcCloseMemHandle(d_canvas));
+    return RTC_OK;
+}
+
 int rtc_render_multi(RtcMulti* multi, const RtcCameraDesc* camera, int32_t depth, int32_t mode, double* out_rgb,
                      RtcStats* stats, RtcMultiTiming* timing) {
     if (!multi) return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "multi is NULL");

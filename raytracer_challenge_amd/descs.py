@@ -29,6 +29,7 @@ RTC_ACCEL_NONE = 0
 RTC_ACCEL_BVH = 1
 RTC_NOALLOC_MAX_TILES = 262144
 RTC_MULTI_MAX_RANKS = 64
+RTC_IPC_HANDLE_BYTES = 64
 RTC_MULTI_PEER_STORES = 0
 RTC_MULTI_PEER_SCATTER = 1
 RTC_MULTI_RCCL_GATHER = 2

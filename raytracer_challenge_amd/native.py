@@ -63,6 +63,9 @@ def lib():
                                    C.POINTER(D.RtcMultiTiming)]
     L.rtc_render_multi_u8.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, i32, C.POINTER(C.c_uint8),
                                       C.POINTER(D.RtcStats), C.POINTER(D.RtcMultiTiming)]
+    L.rtc_ipc_canvas_create.argtypes = [u64, C.POINTER(vp), C.POINTER(C.c_uint8 * D.RTC_IPC_HANDLE_BYTES)]
+    L.rtc_ipc_canvas_open.argtypes = [C.POINTER(C.c_uint8 * D.RTC_IPC_HANDLE_BYTES), C.POINTER(vp)]
+    L.rtc_ipc_canvas_close.argtypes = [vp, i32]
     L.rtc_tile_buffer_doubles.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u32, C.POINTER(u64)]
     L.rtc_deinterleave_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
     L.rtc_deinterleave_u8_device.argtypes = [C.POINTER(D.RtcCameraDesc), u32, u64, vp, vp, vp]
@@ -99,6 +102,9 @@ EXPORTS = (
     "rtc_multi_rank_device",
     "rtc_render_multi",
     "rtc_render_multi_u8",
+    "rtc_ipc_canvas_create",
+    "rtc_ipc_canvas_open",
+    "rtc_ipc_canvas_close",
     "rtc_tile_buffer_doubles",
     "rtc_deinterleave_device",
     "rtc_deinterleave_u8_device",
@@ -176,6 +182,25 @@ def scatter_tiles_device(camera_desc, tile_rank, tile_ranks, d_tiles, d_canvas, 
 
 def scatter_tiles_u8_device(camera_desc, tile_rank, tile_ranks, d_tiles_u8, d_canvas_u8, stream=None):
     check(lib().rtc_scatter_tiles_u8_device(C.byref(camera_desc), tile_rank, tile_ranks, d_tiles_u8, d_canvas_u8, stream))
+
+
+def ipc_canvas_create(n_bytes):
+    """rtc_ipc_canvas_create: (device pointer, handle bytes) of a canvas other processes can map."""
+    p = C.c_void_p(None)
+    h = (C.c_uint8 * D.RTC_IPC_HANDLE_BYTES)()
+    check(lib().rtc_ipc_canvas_create(int(n_bytes), C.byref(p), C.byref(h)))
+    return p.value, bytes(h)
+
+
+def ipc_canvas_open(handle):
+    h = (C.c_uint8 * D.RTC_IPC_HANDLE_BYTES)(*handle)
+    p = C.c_void_p(None)
+    check(lib().rtc_ipc_canvas_open(C.byref(h), C.byref(p)))
+    return p.value
+
+
+def ipc_canvas_close(d_canvas, is_owner):
+    check(lib().rtc_ipc_canvas_close(C.c_void_p(d_canvas), 1 if is_owner else 0))
 
 
 def quantize_u8_device(d_rgb, n_values, d_out_u8, stream=None):

@@ -128,3 +128,28 @@ def test_to_canvas_and_scatter_entry_points():
         assert torch.equal(inplace, full) and torch.equal(scattered, full)
         host = full.cpu().numpy().reshape(vs, hs, 3)
         assert np.array_equal(q_scattered.cpu().numpy().reshape(vs, hs, 3), byte_color_values(host))
+
+
+def test_one_process_per_rank_front_end_with_ipc_canvas():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here
+    with two ranks that share the one GPU and a gloo gather through the host: the f64 gather, the 8-bit
+    gather and the peer-store leg (rank 0's canvas mapped into rank 1 with rtc_ipc_canvas_create/open,
+    rtc_render_device_to_canvas from both processes) must all reproduce the 1-rank canvas."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--workload", "c2", "--rehearse-on-one-gpu", "--verify"],
+        capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2
+    assert out["config"]["canvases_verified_against_1_rank_render"] == {"f64_gather": True, "u8_gather": True,
+                                                                        "peer_stores": True}
