@@ -182,6 +182,8 @@ struct RtcScene {
     uint64_t n = 0;
     uint64_t n_spheres = 0, n_planes = 0, n_cubes = 0;
     double* d_tab = nullptr;
+    double* d_sphere_bounds = nullptr;  // radiance table, then shadow table (see DevWorld)
+    size_t sphere_bounds_doubles = 0;   // doubles per table
     int32_t* d_order = nullptr;
     int32_t group[rtc::kSweepGroups + 1] = {};
     rtc::DevShade* d_shade = nullptr;
@@ -229,6 +231,7 @@ void free_scene(RtcScene* s) {
     if (!s) return;
     if (s->d_tab) (void)hipFree(s->d_tab);
     if (s->d_order) (void)hipFree(s->d_order);
+    if (s->d_sphere_bounds) (void)hipFree(s->d_sphere_bounds);
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->d_tile_order) (void)hipFree(s->d_tile_order);
@@ -245,6 +248,8 @@ rtc::DevWorld dev_world(const RtcScene* s) {
     rtc::DevWorld w{};
     w.tab = s->d_tab;
     w.order = s->d_order;
+    w.sphere_bounds_radiance = s->d_sphere_bounds;
+    w.sphere_bounds_shadow = s->d_sphere_bounds ? s->d_sphere_bounds + s->sphere_bounds_doubles : nullptr;
     std::memcpy(w.group, s->group, sizeof w.group);
     w.shade = s->d_shade;
     w.n = (int32_t)s->n;
@@ -1074,6 +1079,19 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     sc->d_stats = (uint64_t*)((char*)sc->d_counter + rtc::kStatsOffsetBytes);
     SCENE_TRY(hipEventCreate(&sc->ev_start));
     SCENE_TRY(hipEventCreate(&sc->ev_stop));
+    {
+        // side tables of the streamed sphere sweep: the spheres are the first two groups of the table
+        const size_t n_sph = (size_t)group[2];
+        sc->sphere_bounds_doubles = (n_sph + rtc::kSphereBoundsPadding) * 4;
+        std::vector<double> side(2 * sc->sphere_bounds_doubles, 0.0);
+        for (size_t pos = 0; pos < n_sph; ++pos)
+            for (int k = 0; k < 4; ++k) {
+                side[pos * 4 + k] = tab[pos * kRec + 13 + k];
+                side[sc->sphere_bounds_doubles + pos * 4 + k] = tab[pos * kRec + 20 + k];
+            }
+        SCENE_TRY(hipMalloc((void**)&sc->d_sphere_bounds, side.size() * sizeof(double)));
+        SCENE_TRY(hipMemcpy(sc->d_sphere_bounds, side.data(), side.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     SCENE_TRY(hipMalloc((void**)&sc->d_order, order.size() * sizeof(int32_t)));
     SCENE_TRY(hipMemcpy(sc->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     SCENE_TRY(hipMemcpy(sc->d_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));

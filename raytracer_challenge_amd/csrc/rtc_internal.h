@@ -26,6 +26,7 @@ constexpr int kQueueStrideWords = 32;  // uint32 words between queue heads
 constexpr int kStatsOffsetBytes = kQueues * kQueueStrideWords * 4;
 constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 64;
 
+constexpr int kSphereBoundsPadding = 16;  // entries the streamed sweep may read ahead of the last sphere
 constexpr int kRecordDoubles = 24;  // doubles per sweep-table record (see DevWorld)
 
 // The sweep table is grouped by kind of test: one row per group, in table order.  A shape kind
@@ -102,6 +103,10 @@ struct DevWorld {
     const double* tab;
     const DevShade* shade;
     const int32_t* order;
+    // per sphere (table order, starting at table position group[0]) the four numbers of the bounding test: for
+    // radiance rays [13..16] of the record, for shadow rays [20..23]; padded by kSphereBoundsPadding entries
+    const double* sphere_bounds_radiance;
+    const double* sphere_bounds_shadow;
     int32_t n;
     int32_t group[kSweepGroups + 1];
     // acceleration (rtc_scene_set_acceleration): nullptr = every sphere is tested (the reference's list walk)

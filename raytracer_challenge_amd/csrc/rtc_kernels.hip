@@ -357,12 +357,27 @@ __device__ __forceinline__ void cube_axis(double origin, double direction, doubl
     hi = swap ? a : b;
 }
 
+// The bounding-sphere tests (see sweep_shape).  bc/br2: centre and enlarged squared radius of the world-space
+// bounding sphere; lc/lk: the same anchored at the light, for shadow rays (sphere_from_light, rtc_api.hip).
+__device__ __forceinline__ bool sphere_clear_of_ray(const double* bc, double br2, const V3& o, const V3& d, double dd) {
+    const V3 oc = {bc[0] - o.x, bc[1] - o.y, bc[2] - o.z};
+    const double ocd = fma(oc.z, d.z, fma(oc.y, d.y, oc.x * d.x));
+    const double oc2 = fma(oc.z, oc.z, fma(oc.y, oc.y, oc.x * oc.x));
+    const double apart = fma(oc2, kBoundShrink, -br2) * dd;
+    return apart > ocd * ocd;
+}
+__device__ __forceinline__ bool sphere_clear_of_shadow_ray(const double* lc, double lk, const V3& d, double shadow_margin) {
+    // a shadow ray ends at the light: the same test from there, with the sphere's part of it evaluated at upload
+    const double lcd = fma(lc[2], d.z, fma(lc[1], d.y, lc[0] * d.x));
+    return lk - shadow_margin > lcd * lcd;
+}
+
 // One shape against one ray.  The reference's list order decides ties (stable sort by t,
 // ray.zig:75-92): among equal t the shape earlier in the list is the hit, and the one later
 // in the list is the inner container.  The groups are not visited in list order, so ties
 // are resolved explicitly with the list indices (`order`), in the rare branch where two t
 // are equal.
-template <int KIND, bool SHADOW, bool STATS>
+template <int KIND, bool SHADOW, bool STATS, bool BOUND_DONE = false>
 __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const int* __restrict__ order_of,
                                             const V3& o, const V3& d, double dd, double side_scale, double shadow_margin, Sweep& s,
                                             ContainerSlots& cs, SweepCounters& ctr) {
@@ -382,17 +397,12 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
         // (distance^2 - r^2) * |d|^2 > (oc.d)^2, evaluated with fused operations: the margin
         // folded into br2 and kBoundShrink is thousands of times their rounding error.
         bool clear;
-        if (SHADOW) {
-            // a shadow ray ends at the light: the same test from there, with the sphere's part of
-            // it evaluated at upload (sphere_from_light, rtc_api.hip)
-            const double lcd = fma(rec.lc[2], d.z, fma(rec.lc[1], d.y, rec.lc[0] * d.x));
-            clear = rec.lk - shadow_margin > lcd * lcd;
+        if (BOUND_DONE) {
+            clear = false;  // the caller ran the test on the streamed bounds and calls for the lanes that failed it
+        } else if (SHADOW) {
+            clear = sphere_clear_of_shadow_ray(rec.lc, rec.lk, d, shadow_margin);
         } else {
-            const V3 oc = {rec.bc[0] - o.x, rec.bc[1] - o.y, rec.bc[2] - o.z};
-            const double ocd = fma(oc.z, d.z, fma(oc.y, d.y, oc.x * d.x));
-            const double oc2 = fma(oc.z, oc.z, fma(oc.y, oc.y, oc.x * oc.x));
-            const double apart = fma(oc2, kBoundShrink, -rec.br2) * dd;
-            clear = apart > ocd * ocd;
+            clear = sphere_clear_of_ray(rec.bc, rec.br2, o, d, dd);
         }
         if (STATS && clear) ++ctr.sphere_skips;
         if (!clear) {
@@ -568,6 +578,68 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
     }
 }
 
+// The spheres of a large world (more shapes than the LDS tables hold).  Nearly every (ray, sphere) pair of
+// such a world ends at the bounding test, which needs four numbers of the sphere (centre and radius term;
+// for a shadow ray the light-anchored pair), not the 24 of its record.  Those four are kept in two dense
+// side tables (32 bytes per sphere, table order, one for each kind of ray) that are streamed through the
+// scalar cache four spheres per request, two requests ahead; the full record is fetched (a scalar load
+// whose latency is then exposed) only for a sphere some lane of the wave cannot dismiss.  Per sphere the
+// sweep moves 32 instead of 192 bytes from the L2 and issues a quarter of a load instruction instead of
+// three; what is evaluated, and in which order, is unchanged.
+struct Bounds4 {
+    double v[16];
+};
+__device__ __forceinline__ Bounds4 load_bounds4(const double* __restrict__ p) {
+    Bounds4 r;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r.v[k] = p[k];
+    return r;
+}
+template <bool SHADOW, bool STATS>
+__device__ __forceinline__ void sweep_spheres_streamed(const double* __restrict__ bounds, const double* __restrict__ tab,
+                                                       const int* __restrict__ order_of, int begin, int split, int end,
+                                                       const V3& o, const V3& d, double dd, double shadow_margin,
+                                                       Sweep& s, ContainerSlots& cs, SweepCounters& ctr) {
+    if (begin >= end) return;
+    // the full test of sphere i for the lanes whose bounding test did not dismiss it
+    auto full = [&](int i, bool clear) {
+        if (i < end && !clear) {  // (the tables are padded: the padding is not a shape)
+            const ShapeRec rec = load_rec(tab, i);
+            if (i < split)  // the spheres with a diagonal inverse come first
+                sweep_shape<kSphereAxis, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+            else
+                sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+        }
+    };
+    // four spheres: their bounding tests back to back (independent chains), one branch for the four
+    auto four = [&](const double* b, int i) {
+        bool clear[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            clear[k] = SHADOW ? sphere_clear_of_shadow_ray(b + 4 * k, b[4 * k + 3], d, shadow_margin)
+                              : sphere_clear_of_ray(b + 4 * k, b[4 * k + 3], o, d, dd);
+        if (STATS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (clear[k] && i + k < end) ++ctr.sphere_skips;
+        }
+        if (!(clear[0] && clear[1] && clear[2] && clear[3])) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) full(i + k, clear[k]);
+        }
+    };
+    const double* __restrict__ p = bounds + (size_t)begin * 4;
+    Bounds4 A = load_bounds4(p);
+    for (int i = begin; i < end; i += 8, p += 32) {
+        asm volatile("" ::"s"(A.v[15]) : "memory");
+        const Bounds4 B = load_bounds4(p + 16);
+        four(A.v, i);
+        asm volatile("" ::"s"(B.v[15]) : "memory");
+        A = load_bounds4(p + 32);
+        four(B.v, i + 4);
+    }
+}
+
 // The spheres through the optional hierarchy (rtc_scene_set_acceleration) instead of the two
 // sphere loops.  Each lane walks the tree with its own ray: a node carries the (enlarged) boxes
 // of both children; a child is entered when the slab test cannot rule out that the ray crosses
@@ -650,10 +722,10 @@ __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab
 
 // SHADOW: s.t holds the distance to the light on entry and only roots in [0, s.t) are
 // accepted (calc.zig:789: hit.t < distance); containers are not tracked.
-template <bool SHADOW, bool STATS, bool ACCEL>
+template <bool SHADOW, bool STATS, bool ACCEL, bool STREAM>
 __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, const int* __restrict__ order_of,
-                                            const DevWorld& w, const V3& o, const V3& d, Sweep& s, ContainerSlots& cs,
-                                            SweepCounters& ctr) {
+                                            const double* __restrict__ sphere_bounds, const DevWorld& w, const V3& o,
+                                            const V3& d, Sweep& s, ContainerSlots& cs, SweepCounters& ctr) {
     const int tid = (int)threadIdx.x;
     const double dd = fma(d.z, d.z, fma(d.y, d.y, d.x * d.x));  // for the bounding-sphere tests
     // for the same-side test of the planes: 1 + |o|_1 + |light|_1 bounds every magnitude in it
@@ -671,6 +743,9 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     sweep_group<kCube, SHADOW, STATS>(tab, order_of, w.group[4], w.group[5], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     if (ACCEL) {
         if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, shadow_margin, s, cs, ctr);
+    } else if (STREAM) {
+        sweep_spheres_streamed<SHADOW, STATS>(sphere_bounds, tab, order_of, w.group[0], w.group[1], w.group[2], o, d, dd,
+                                              shadow_margin, s, cs, ctr);
     } else {
         sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
         sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
@@ -782,9 +857,9 @@ static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
 // instruction (v_readlane) per 32 bits.  Reading them from the kernel-argument segment where
 // they are used costs a few scalar loads instead (the segment stays in the scalar cache); the
 // empty asm makes the address opaque, so that the loads are not hoisted out of the loop again.
-// Layout of the segment: the eight pointers, then DevWorld, then DevJob (checked against the
+// Layout of the segment: the ten pointers, then DevWorld, then DevJob (checked against the
 // code object's metadata by the build's assembly listing).
-constexpr int kWorldArgOffset = 8 * 8;
+constexpr int kWorldArgOffset = 10 * 8;
 constexpr int kJobArgOffset = kWorldArgOffset + (int)sizeof(DevWorld);
 static_assert(sizeof(DevWorld) % 8 == 0 && alignof(DevJob) == 8 && alignof(DevWorld) == 8, "kernel-argument layout");
 typedef const __attribute__((address_space(4))) DevJob* JobArg;
@@ -816,10 +891,13 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                                                         const double* __restrict__ g_rays,
                                                         const uint32_t* __restrict__ g_tile_order,
                                                         double* __restrict__ g_out, uint32_t* __restrict__ g_counter,
-                                                        unsigned long long* __restrict__ g_stats, const DevWorld wc,
+                                                        unsigned long long* __restrict__ g_stats,
+                                                        const double* __restrict__ g_bounds_r,
+                                                        const double* __restrict__ g_bounds_s, const DevWorld wc,
                                                         const DevJob job) {
     constexpr bool LDS = TABLES == 1;
     constexpr bool ACCEL = TABLES == 2;
+    constexpr bool STREAM = TABLES == 0;  // large world, list walk: the spheres' bounds are streamed from their side tables
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS> hot;
     __shared__ FrameSlots frames;
@@ -1133,7 +1211,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
             const int remaining = ((aux >> kAuxRemShift) & 63) - sp;
             Sweep hit;
-            sweep_world<false, STATS, ACCEL>(sweep_tab, g_order, w, ro, rd, hit, containers, ctr);
+            sweep_world<false, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_r, w, ro, rd, hit, containers, ctr);
             RTC_STAMP(pc_sweep1);
 
             have_ret = true;
@@ -1194,7 +1272,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 Sweep sh_hit;
                 sh_hit.t = distance;
                 RTC_STAMP(pc_prep);
-                sweep_world<true, STATS, ACCEL>(sweep_tab, g_order, w, over_point, lightv, sh_hit, containers, ctr);
+                sweep_world<true, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_s, w, over_point, lightv, sh_hit, containers, ctr);
                 RTC_STAMP(pc_sweep2);
                 const bool in_shadow = sh_hit.idx >= 0;
 
@@ -1500,7 +1578,8 @@ hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t s
     if (blocks > needed) blocks = needed;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.tab, world.shade, world.order, job.rays,
-                       job.tile_order, job.out, job.counter, (unsigned long long*)job.stats, world, job);
+                       job.tile_order, job.out, job.counter, (unsigned long long*)job.stats, world.sphere_bounds_radiance,
+                       world.sphere_bounds_shadow, world, job);
     return hipGetLastError();
 }
 
