@@ -322,8 +322,8 @@ double stretch_bound(const double* m, int stride) {
 }
 
 // World-space bounding sphere of a sphere shape for the sweep's early-out: out[0..2] centre,
-// out[3] squared radius plus the error margin.  The sweep skips a (ray, sphere) pair when
-//     (|c - o|^2 (1 - 2^-27) - out[3]) |d|^2 > ((c - o).d)^2 ,
+// out[3] squared radius plus the error margin, divided by 1 - 2^-27.  The sweep skips a (ray, sphere) pair when
+//     (|c - o|^2 (1 - 2^-27) - bound) |d|^2 > ((c - o).d)^2 ,   evaluated as (|c - o|^2 - out[3]) (|d|^2 (1 - 2^-27)),
 // i.e. when the line passes the bounding sphere by more than 2^-28 (|o|^2 + |c|^2 + r^2) in squared
 // distance (|o|^2 <= 2|c - o|^2 + 2|c|^2).  In exact arithmetic on the stored inverse the
 // reference's discriminant is 4|ld|^2 (1 - (distance/r')^2) < 0 there (r' <= r the extent of the
@@ -346,7 +346,9 @@ void sphere_bound(const RtcShapeDesc& s, const double* inv12, double* out) {
     out[0] = t[3];
     out[1] = t[7];
     out[2] = t[11];
-    out[3] = bound;
+    // stored divided by the test's shrink factor 1 - 2^-27 (the device multiplies |d|^2 by it instead of
+    // |c - o|^2), rounded up so that the stored bound is never the smaller one
+    out[3] = std::nextafter(bound / (1.0 - 0x1p-27), std::numeric_limits<double>::infinity());
 }
 
 // Box around the enlarged bounding sphere of sphere_bound (centre b[0..2], squared radius b[3]):

@@ -359,11 +359,13 @@ __device__ __forceinline__ void cube_axis(double origin, double direction, doubl
 
 // The bounding-sphere tests (see sweep_shape).  bc/br2: centre and enlarged squared radius of the world-space
 // bounding sphere; lc/lk: the same anchored at the light, for shadow rays (sphere_from_light, rtc_api.hip).
-__device__ __forceinline__ bool sphere_clear_of_ray(const double* bc, double br2, const V3& o, const V3& d, double dd) {
+__device__ __forceinline__ bool sphere_clear_of_ray(const double* bc, double br2, const V3& o, const V3& d, double dds) {
     const V3 oc = {bc[0] - o.x, bc[1] - o.y, bc[2] - o.z};
     const double ocd = fma(oc.z, d.z, fma(oc.y, d.y, oc.x * d.x));
     const double oc2 = fma(oc.z, oc.z, fma(oc.y, oc.y, oc.x * oc.x));
-    const double apart = fma(oc2, kBoundShrink, -br2) * dd;
+    // br2 holds the enlarged squared radius already divided by kBoundShrink and dds = |d|^2 kBoundShrink:
+    // (oc2 kBoundShrink - r2) |d|^2 with one scalar operand per instruction
+    const double apart = (oc2 - br2) * dds;
     return apart > ocd * ocd;
 }
 __device__ __forceinline__ bool sphere_clear_of_shadow_ray(const double* lc, double lk, const V3& d, double shadow_margin) {
@@ -612,20 +614,24 @@ __device__ __forceinline__ void sweep_spheres_streamed(const double* __restrict_
         }
     };
     // four spheres: their bounding tests back to back (independent chains), one branch for the four
+    auto test = [&](const double* b) -> bool {
+        return SHADOW ? sphere_clear_of_shadow_ray(b, b[3], d, shadow_margin) : sphere_clear_of_ray(b, b[3], o, d, dd);
+    };
     auto four = [&](const double* b, int i) {
-        bool clear[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            clear[k] = SHADOW ? sphere_clear_of_shadow_ray(b + 4 * k, b[4 * k + 3], d, shadow_margin)
-                              : sphere_clear_of_ray(b + 4 * k, b[4 * k + 3], o, d, dd);
+        // (four named flags, not an array: an array of flags is kept as bytes in a vector register and costs
+        // a handful of instructions per test to pack and unpack)
+        const bool c0 = test(b), c1 = test(b + 4), c2 = test(b + 8), c3 = test(b + 12);
         if (STATS) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (clear[k] && i + k < end) ++ctr.sphere_skips;
+            if (c0 && i < end) ++ctr.sphere_skips;
+            if (c1 && i + 1 < end) ++ctr.sphere_skips;
+            if (c2 && i + 2 < end) ++ctr.sphere_skips;
+            if (c3 && i + 3 < end) ++ctr.sphere_skips;
         }
-        if (!(clear[0] && clear[1] && clear[2] && clear[3])) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) full(i + k, clear[k]);
+        if (!(c0 && c1 && c2 && c3)) {
+            full(i, c0);
+            full(i + 1, c1);
+            full(i + 2, c2);
+            full(i + 3, c3);
         }
     };
     const double* __restrict__ p = bounds + (size_t)begin * 4;
@@ -727,7 +733,8 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
                                             const double* __restrict__ sphere_bounds, const DevWorld& w, const V3& o,
                                             const V3& d, Sweep& s, ContainerSlots& cs, SweepCounters& ctr) {
     const int tid = (int)threadIdx.x;
-    const double dd = fma(d.z, d.z, fma(d.y, d.y, d.x * d.x));  // for the bounding-sphere tests
+    // for the bounding-sphere tests: |d|^2, scaled by the shrink factor of the test (see sphere_clear_of_ray)
+    const double dd = fma(d.z, d.z, fma(d.y, d.y, d.x * d.x)) * kBoundShrink;
     // for the same-side test of the planes: 1 + |o|_1 + |light|_1 bounds every magnitude in it
     const double side_scale = SHADOW ? ((fabs(o.x) + fabs(o.y)) + fabs(o.z)) + w.light_reach : 0.0;
     // the per-ray term of the spheres' test from the light: 2^-25 dist^2 (s.t is the distance on entry)
