@@ -182,6 +182,7 @@ struct RtcScene {
     uint64_t n = 0;
     uint64_t n_spheres = 0, n_planes = 0, n_cubes = 0;
     double* d_tab = nullptr;
+    double* d_inv = nullptr;            // rows 0..2 of inverse(shape.transform), 12 doubles per shape, table order
     double* d_sphere_bounds = nullptr;  // radiance table, then shadow table (see DevWorld)
     size_t sphere_bounds_doubles = 0;   // doubles per table
     int32_t* d_order = nullptr;
@@ -207,6 +208,7 @@ struct RtcScene {
     };
     struct SphereBound {
         double b[4];  // centre and enlarged squared radius, as in the sweep table
+        double from_light[4];
         int32_t pos;
     };
     std::vector<SphereBound> sphere_bounds;  // kept from rtc_scene_create
@@ -232,6 +234,7 @@ void free_scene(RtcScene* s) {
     if (s->d_tab) (void)hipFree(s->d_tab);
     if (s->d_order) (void)hipFree(s->d_order);
     if (s->d_sphere_bounds) (void)hipFree(s->d_sphere_bounds);
+    if (s->d_inv) (void)hipFree(s->d_inv);
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->d_tile_order) (void)hipFree(s->d_tile_order);
@@ -248,6 +251,7 @@ rtc::DevWorld dev_world(const RtcScene* s) {
     rtc::DevWorld w{};
     w.tab = s->d_tab;
     w.order = s->d_order;
+    w.inv = s->d_inv;
     w.sphere_bounds_radiance = s->d_sphere_bounds;
     w.sphere_bounds_shadow = s->d_sphere_bounds ? s->d_sphere_bounds + s->sphere_bounds_doubles : nullptr;
     std::memcpy(w.group, s->group, sizeof w.group);
@@ -1009,6 +1013,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     std::vector<RtcScene::SphereBound> bounds;
     // table order: the four groups one after the other, each in list order
     std::vector<double> tab((n_shapes + 2) * kRec, 0.0);
+    std::vector<double> inv_tab((n_shapes ? n_shapes : 1) * 12, 0.0);  // rows 0..2 of every inverse, table order (gathers)
     std::vector<int32_t> order(n_shapes ? n_shapes : 1, 0);
     std::vector<rtc::DevShade> shade_tab(n_shapes);
     int32_t group[rtc::kSweepGroups + 1] = {};
@@ -1018,18 +1023,51 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
             group[g] = (int32_t)pos;
             for (uint64_t i = 0; i < n_shapes; ++i) {
                 if (group_of[i] != g) continue;
-                std::memcpy(&tab[pos * kRec], &inv12[i * 12], 12 * sizeof(double));
+                // the record of the shape in its group's layout (rtc_internal.h: kRec*), what each kind of sweep
+                // reads side by side so that it arrives with one or two scalar loads
+                const double* m = &inv12[i * 12];
+                double* rec = &tab[pos * kRec];
                 const int64_t order_word = (int64_t)i;
-                std::memcpy(&tab[pos * kRec + 12], &order_word, sizeof order_word);
-                sphere_bound(shapes[i], &inv12[i * 12], &tab[pos * kRec + 13]);
-                if (shapes[i].geo == RTC_GEO_PLANE) plane_light_side(&inv12[i * 12], light->position, &tab[pos * kRec + 17]);
-                if (shapes[i].geo == RTC_GEO_SPHERE) sphere_from_light(&tab[pos * kRec + 13], light->position, &tab[pos * kRec + 20]);
+                double order_as_double;
+                std::memcpy(&order_as_double, &order_word, sizeof order_word);
+                double bound[4] = {0, 0, 0, std::numeric_limits<double>::infinity()}, from_light[4] = {0, 0, 0, 0}, side[3] = {0, 0, 0};
+                sphere_bound(shapes[i], m, bound);
+                if (shapes[i].geo == RTC_GEO_PLANE) plane_light_side(m, light->position, side);
+                if (shapes[i].geo == RTC_GEO_SPHERE) sphere_from_light(bound, light->position, from_light);
+                switch (g) {
+                    case 0:  // sphere, diagonal inverse
+                        for (int k = 0; k < 6; ++k) rec[rtc::kRecAxisSphereM + k] = rec[rtc::kRecAxisSphereShadowM + k] = m[rtc::kAxisSphereEntries[k]];
+                        rec[rtc::kRecAxisSphereOrder] = order_as_double;
+                        rec[rtc::kRecAxisSphereBr2] = bound[3];
+                        for (int k = 0; k < 3; ++k) rec[rtc::kRecAxisSphereBc + k] = bound[k];
+                        for (int k = 0; k < 4; ++k) rec[rtc::kRecAxisSphereLight + k] = from_light[k];
+                        break;
+                    case 2:  // plane, inverse row 1 = (0, m5, 0, m7)
+                        rec[rtc::kRecAxisPlaneM] = m[5];
+                        rec[rtc::kRecAxisPlaneM + 1] = m[7];
+                        rec[rtc::kRecAxisPlaneOrder] = order_as_double;
+                        for (int k = 0; k < 3; ++k) rec[rtc::kRecAxisPlaneLight + k] = side[k];
+                        break;
+                    case 3:  // plane
+                        for (int k = 0; k < 4; ++k) rec[rtc::kRecPlaneM + k] = m[4 + k];
+                        rec[rtc::kRecPlaneOrder] = order_as_double;
+                        for (int k = 0; k < 3; ++k) rec[rtc::kRecPlaneLight + k] = side[k];
+                        break;
+                    default:  // sphere (1) and cube (4): the whole inverse first
+                        std::memcpy(rec, m, 12 * sizeof(double));
+                        rec[rtc::kRecFullOrder] = order_as_double;
+                        for (int k = 0; k < 4; ++k) rec[rtc::kRecFullBound + k] = bound[k];
+                        for (int k = 0; k < 4; ++k) rec[rtc::kRecFullLight + k] = from_light[k];
+                        break;
+                }
                 if (shapes[i].geo == RTC_GEO_SPHERE) {
                     RtcScene::SphereBound sb;
-                    std::memcpy(sb.b, &tab[pos * kRec + 13], sizeof sb.b);
+                    std::memcpy(sb.b, bound, sizeof sb.b);
+                    std::memcpy(sb.from_light, from_light, sizeof sb.from_light);
                     sb.pos = (int32_t)pos;
                     bounds.push_back(sb);
                 }
+                std::memcpy(&inv_tab[pos * 12], m, 12 * sizeof(double));
                 order[pos] = (int32_t)i;
                 shade_tab[pos] = shade[i];
                 ++pos;
@@ -1086,14 +1124,16 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         const size_t n_sph = (size_t)group[2];
         sc->sphere_bounds_doubles = (n_sph + rtc::kSphereBoundsPadding) * 4;
         std::vector<double> side(2 * sc->sphere_bounds_doubles, 0.0);
-        for (size_t pos = 0; pos < n_sph; ++pos)
+        for (const RtcScene::SphereBound& sb : sc->sphere_bounds)  // (the spheres' table positions are 0 .. n_sph - 1)
             for (int k = 0; k < 4; ++k) {
-                side[pos * 4 + k] = tab[pos * kRec + 13 + k];
-                side[sc->sphere_bounds_doubles + pos * 4 + k] = tab[pos * kRec + 20 + k];
+                side[(size_t)sb.pos * 4 + k] = sb.b[k];
+                side[sc->sphere_bounds_doubles + (size_t)sb.pos * 4 + k] = sb.from_light[k];
             }
         SCENE_TRY(hipMalloc((void**)&sc->d_sphere_bounds, side.size() * sizeof(double)));
         SCENE_TRY(hipMemcpy(sc->d_sphere_bounds, side.data(), side.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    SCENE_TRY(hipMalloc((void**)&sc->d_inv, inv_tab.size() * sizeof(double)));
+    SCENE_TRY(hipMemcpy(sc->d_inv, inv_tab.data(), inv_tab.size() * sizeof(double), hipMemcpyHostToDevice));
     SCENE_TRY(hipMalloc((void**)&sc->d_order, order.size() * sizeof(int32_t)));
     SCENE_TRY(hipMemcpy(sc->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     SCENE_TRY(hipMemcpy(sc->d_order, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -26,6 +26,19 @@ constexpr int kQueueStrideWords = 32;  // uint32 words between queue heads
 constexpr int kStatsOffsetBytes = kQueues * kQueueStrideWords * 4;
 constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 64;
 
+// Layout of a sweep-table record (kRecordDoubles doubles) per group: every sweep reads a contiguous run.
+//   sphere with a diagonal inverse: [0..5] m0 m3 m5 m7 m10 m11, [6] list index, [7] bound radius term, [8..10] bound
+//       centre — the radiance sweep's run [0..10]; [12..17] the six entries again, [18..21] light-anchored bound —
+//       the shadow sweep's run [12..21]
+//   plane with row 1 = (0, m5, 0, m7): [0] m5, [1] m7, [2] list index, [4..6] light side, light height, guard
+//   plane: [0..3] m4..m7, [4] list index, [5..7] light side, light height, guard
+//   sphere, cube: [0..11] rows 0..2 of the inverse, [12] list index, [13..16] bound, [20..23] light-anchored bound
+constexpr int kAxisSphereEntries[6] = {0, 3, 5, 7, 10, 11};
+constexpr int kRecAxisSphereM = 0, kRecAxisSphereOrder = 6, kRecAxisSphereBr2 = 7, kRecAxisSphereBc = 8,
+              kRecAxisSphereShadowM = 12, kRecAxisSphereLight = 18;
+constexpr int kRecAxisPlaneM = 0, kRecAxisPlaneOrder = 2, kRecAxisPlaneLight = 4;
+constexpr int kRecPlaneM = 0, kRecPlaneOrder = 4, kRecPlaneLight = 5;
+constexpr int kRecFullOrder = 12, kRecFullBound = 13, kRecFullLight = 20;
 constexpr int kSphereBoundsPadding = 16;  // entries the streamed sweep may read ahead of the last sphere
 constexpr int kRecordDoubles = 24;  // doubles per sweep-table record (see DevWorld)
 
@@ -77,15 +90,15 @@ struct DevShade {
 // The shapes are stored in "table order": four groups (spheres whose inverse is diagonal,
 // other spheres, planes whose inverse row 1 is (0,m,0,t), other planes), each group in the
 // reference's list order.  group[g]..group[g+1] are the table positions of group g.
-//   tab   : (n+2) x 24 doubles, one 192-byte record per shape: [0..11] rows 0..2 of
-//           inverse(shape.transform), row-major 3x4; [12] the shape's index in the reference's
-//           list (an integer in the low bits of the word); [13..15] centre and [16] enlarged
-//           squared radius of a world-space bounding sphere (spheres only; +inf = none);
-//           [17..19] planes only: side of the plane the light is on (+1, -1, 0 = unknown),
-//           |local y of the light|, guard factor 2^-32 max(|m4|+|m5|+|m6|, |m7|);
-//           [20..23] spheres only, for shadow rays (which all end at the light): bounding-sphere
-//           centre minus light position, and |that|^2 (1 - 2^-25) - [16] (1 + 2^-40).  The sweep reads it with wave-uniform addresses, up to two
-//           records ahead, hence two padding records.
+//   tab   : (n+2) x 24 doubles, one 192-byte record per shape, laid out per group (kRec* above) so that what
+//           a sweep reads of it is one contiguous run: the entries of rows 0..2 of inverse(shape.transform)
+//           the group's test multiplies in, the shape's index in the reference's list (an integer in the
+//           low bits of a word), centre and enlarged squared radius (divided by the test's shrink factor)
+//           of a world-space bounding sphere (spheres only; +inf = none); planes: side of the plane the
+//           light is on (+1, -1, 0 = unknown), |local y of the light|, guard factor
+//           2^-32 max(|m4|+|m5|+|m6|, |m7|); spheres, for shadow rays (which all end at the light):
+//           bounding-sphere centre minus light position, and |that|^2 (1 - 2^-25) - bound (1 + 2^-40).
+//           The sweep reads it with wave-uniform addresses, up to two records ahead, hence two padding records.
 //   shade : n x DevShade, table order — gathered per lane at a hit.
 //   order : n x int32, table position -> list index (tie-breaks between equal t).
 // Node of the optional bounding-volume hierarchy over the spheres (128 B): the boxes of both
@@ -103,6 +116,7 @@ struct DevWorld {
     const double* tab;
     const DevShade* shade;
     const int32_t* order;
+    const double* inv;  // n x 12 doubles: rows 0..2 of inverse(shape.transform), table order — gathered per lane at a hit
     // per sphere (table order, starting at table position group[0]) the four numbers of the bounding test: for
     // radiance rays [13..16] of the record, for shadow rays [20..23]; padded by kSphereBoundsPadding entries
     const double* sphere_bounds_radiance;

@@ -299,25 +299,42 @@ struct ShapeRec {
     double lc[3];
     double lk;
 };
-// Wave-uniform read of the record at table position i (scalar loads); the table ends with
-// padding records so that reading ahead is always in bounds.
+// Wave-uniform read of the record at table position i (scalar loads): what the sweep of the record's group
+// reads, from where the group's layout keeps it (rtc_internal.h); the table ends with padding records so that
+// reading ahead is always in bounds.
+enum : int { kSphereAxis = 0, kSphereGeneral = 1, kPlaneAxis = 2, kPlaneGeneral = 3, kCube = 4 };
+template <int KIND, bool SHADOW>
 __device__ __forceinline__ ShapeRec load_rec(const double* __restrict__ tab, int i) {
     ShapeRec r;
     const double* __restrict__ p = tab + (size_t)i * kRecDoubles;
+    if (KIND == kSphereAxis) {
+        const double* __restrict__ m = p + (SHADOW ? kRecAxisSphereShadowM : kRecAxisSphereM);
+        r.m[0] = m[0], r.m[3] = m[1], r.m[5] = m[2], r.m[7] = m[3], r.m[10] = m[4], r.m[11] = m[5];
+        if (SHADOW) {
+            r.lc[0] = p[kRecAxisSphereLight], r.lc[1] = p[kRecAxisSphereLight + 1], r.lc[2] = p[kRecAxisSphereLight + 2];
+            r.lk = p[kRecAxisSphereLight + 3];
+        } else {
+            r.order = __double_as_longlong(p[kRecAxisSphereOrder]);
+            r.br2 = p[kRecAxisSphereBr2];
+            r.bc[0] = p[kRecAxisSphereBc], r.bc[1] = p[kRecAxisSphereBc + 1], r.bc[2] = p[kRecAxisSphereBc + 2];
+        }
+    } else if (KIND == kPlaneAxis) {
+        r.m[5] = p[kRecAxisPlaneM], r.m[7] = p[kRecAxisPlaneM + 1];
+        r.order = __double_as_longlong(p[kRecAxisPlaneOrder]);
+        r.light_side = p[kRecAxisPlaneLight], r.light_height = p[kRecAxisPlaneLight + 1], r.side_guard = p[kRecAxisPlaneLight + 2];
+    } else if (KIND == kPlaneGeneral) {
+        r.m[4] = p[kRecPlaneM], r.m[5] = p[kRecPlaneM + 1], r.m[6] = p[kRecPlaneM + 2], r.m[7] = p[kRecPlaneM + 3];
+        r.order = __double_as_longlong(p[kRecPlaneOrder]);
+        r.light_side = p[kRecPlaneLight], r.light_height = p[kRecPlaneLight + 1], r.side_guard = p[kRecPlaneLight + 2];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) r.m[k] = p[k];
-    r.order = __double_as_longlong(p[12]);
-    r.bc[0] = p[13];
-    r.bc[1] = p[14];
-    r.bc[2] = p[15];
-    r.br2 = p[16];
-    r.light_side = p[17];
-    r.light_height = p[18];
-    r.side_guard = p[19];
-    r.lc[0] = p[20];
-    r.lc[1] = p[21];
-    r.lc[2] = p[22];
-    r.lk = p[23];
+        for (int k = 0; k < 12; ++k) r.m[k] = p[k];
+        r.order = __double_as_longlong(p[kRecFullOrder]);
+        r.bc[0] = p[kRecFullBound], r.bc[1] = p[kRecFullBound + 1], r.bc[2] = p[kRecFullBound + 2];
+        r.br2 = p[kRecFullBound + 3];
+        r.lc[0] = p[kRecFullLight], r.lc[1] = p[kRecFullLight + 1], r.lc[2] = p[kRecFullLight + 2];
+        r.lk = p[kRecFullLight + 3];
+    }
     return r;
 }
 
@@ -333,7 +350,6 @@ struct ContainerSlots {
 // The table holds the shapes in four groups, each in list order, so that each group is
 // swept by a loop specialised for it: no per-shape dispatch, and the zero entries of
 // axis-aligned inverses are never multiplied.
-enum : int { kSphereAxis = 0, kSphereGeneral = 1, kPlaneAxis = 2, kPlaneGeneral = 3, kCube = 4 };
 static_assert(kSweepGroupTable[kSphereAxis].geo == RTC_GEO_SPHERE && kSweepGroupTable[kSphereAxis].axis_aligned &&
                   kSweepGroupTable[kSphereGeneral].geo == RTC_GEO_SPHERE && kSweepGroupTable[kPlaneAxis].geo == RTC_GEO_PLANE &&
                   kSweepGroupTable[kPlaneAxis].axis_aligned && kSweepGroupTable[kPlaneGeneral].geo == RTC_GEO_PLANE &&
@@ -561,21 +577,13 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
                                             int end, const V3& o, const V3& d, double dd, double side_scale, double shadow_margin, Sweep& s,
                                             ContainerSlots& cs, SweepCounters& ctr) {
     if (begin >= end) return;
-    ShapeRec A = load_rec(tab, begin);
+    ShapeRec A = load_rec<KIND, SHADOW>(tab, begin);
     for (int i = begin; i < end; i += 2) {
-#ifdef RTC_LDS_SWEEP
-        asm volatile("" ::"v"(A.order) : "memory");
-#else
-        asm volatile("" ::"s"(A.order) : "memory");
-#endif
-        const ShapeRec B = load_rec(tab, i + 1);
+        asm volatile("" ::"s"(A.m[5]) : "memory");  // (an entry every layout loads)
+        const ShapeRec B = load_rec<KIND, SHADOW>(tab, i + 1);
         sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, dd, side_scale, shadow_margin, s, cs, ctr);
-#ifdef RTC_LDS_SWEEP
-        asm volatile("" ::"v"(B.order) : "memory");
-#else
-        asm volatile("" ::"s"(B.order) : "memory");
-#endif
-        A = load_rec(tab, i + 2);
+        asm volatile("" ::"s"(B.m[5]) : "memory");
+        A = load_rec<KIND, SHADOW>(tab, i + 2);
         if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     }
 }
@@ -606,11 +614,12 @@ __device__ __forceinline__ void sweep_spheres_streamed(const double* __restrict_
     // the full test of sphere i for the lanes whose bounding test did not dismiss it
     auto full = [&](int i, bool clear) {
         if (i < end && !clear) {  // (the tables are padded: the padding is not a shape)
-            const ShapeRec rec = load_rec(tab, i);
             if (i < split)  // the spheres with a diagonal inverse come first
-                sweep_shape<kSphereAxis, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                sweep_shape<kSphereAxis, SHADOW, STATS, true>(load_rec<kSphereAxis, SHADOW>(tab, i), i, order_of, o, d, dd, 0.0,
+                                                              shadow_margin, s, cs, ctr);
             else
-                sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                sweep_shape<kSphereGeneral, SHADOW, STATS, true>(load_rec<kSphereGeneral, SHADOW>(tab, i), i, order_of, o, d, dd,
+                                                                 0.0, shadow_margin, s, cs, ctr);
         }
     };
     // four spheres: their bounding tests back to back (independent chains), one branch for the four
@@ -672,12 +681,13 @@ __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab
     for (;;) {
         if (cur < 0) {
             const int pos = ~cur;
-            const ShapeRec rec = load_rec(tab, pos);
             // the table keeps the spheres with a diagonal inverse first: they need six of the twelve entries
             if (pos < w.group[1])
-                sweep_shape<kSphereAxis, SHADOW, STATS>(rec, pos, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                sweep_shape<kSphereAxis, SHADOW, STATS>(load_rec<kSphereAxis, SHADOW>(tab, pos), pos, order_of, o, d, dd, 0.0,
+                                                        shadow_margin, s, cs, ctr);
             else
-                sweep_shape<kSphereGeneral, SHADOW, STATS>(rec, pos, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                sweep_shape<kSphereGeneral, SHADOW, STATS>(load_rec<kSphereGeneral, SHADOW>(tab, pos), pos, order_of, o, d, dd, 0.0,
+                                                           shadow_margin, s, cs, ctr);
             if (SHADOW && s.idx >= 0) break;  // calc.isShadowed only asks whether anything is in the way
         } else {
             const BvhNode* __restrict__ n = w.bvh + cur;
@@ -840,20 +850,12 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
 // and its material/pattern record) in LDS, copied once per workgroup: a gather then costs an
 // LDS access instead of a chain of dependent trips to the L2, which four waves per SIMD
 // cannot hide.  Larger worlds spend their time in the sweeps and gather from global memory.
-#ifdef RTC_LDS_SWEEP
-// developer experiment: the whole sweep record in LDS, read with wave-uniform LDS addresses (a
-// broadcast into vector registers) instead of scalar loads into scalar registers
-constexpr int kLdsShapes = 16;
-constexpr int kHotMatDoubles = kRecDoubles;
-#else
 constexpr int kLdsShapes = 32;
-constexpr int kHotMatDoubles = 12;
-#endif
 template <bool ON>
 struct HotTables {};
 template <>
 struct HotTables<true> {
-    double mat[kLdsShapes + (kHotMatDoubles == 12 ? 0 : 2)][kHotMatDoubles];
+    double mat[kLdsShapes][12];
     DevShade shade[kLdsShapes];
 };
 static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
@@ -864,9 +866,9 @@ static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
 // instruction (v_readlane) per 32 bits.  Reading them from the kernel-argument segment where
 // they are used costs a few scalar loads instead (the segment stays in the scalar cache); the
 // empty asm makes the address opaque, so that the loads are not hoisted out of the loop again.
-// Layout of the segment: the ten pointers, then DevWorld, then DevJob (checked against the
+// Layout of the segment: the eleven pointers, then DevWorld, then DevJob (checked against the
 // code object's metadata by the build's assembly listing).
-constexpr int kWorldArgOffset = 10 * 8;
+constexpr int kWorldArgOffset = 11 * 8;
 constexpr int kJobArgOffset = kWorldArgOffset + (int)sizeof(DevWorld);
 static_assert(sizeof(DevWorld) % 8 == 0 && alignof(DevJob) == 8 && alignof(DevWorld) == 8, "kernel-argument layout");
 typedef const __attribute__((address_space(4))) DevJob* JobArg;
@@ -900,7 +902,8 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                                                         double* __restrict__ g_out, uint32_t* __restrict__ g_counter,
                                                         unsigned long long* __restrict__ g_stats,
                                                         const double* __restrict__ g_bounds_r,
-                                                        const double* __restrict__ g_bounds_s, const DevWorld wc,
+                                                        const double* __restrict__ g_bounds_s,
+                                                        const double* __restrict__ g_inv, const DevWorld wc,
                                                         const DevJob job) {
     constexpr bool LDS = TABLES == 1;
     constexpr bool ACCEL = TABLES == 2;
@@ -911,9 +914,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     const int tid = (int)threadIdx.x;
     if constexpr (LDS) {
         const int n = wc.n;
-        constexpr int kW = kHotMatDoubles;
-        const int rows = kW == 12 ? n : n + 2;  // with whole records: the two padding records as well
-        for (int k = (int)threadIdx.x; k < rows * kW; k += kBlock) hot.mat[k / kW][k % kW] = g_tab[(k / kW) * kRecDoubles + k % kW];
+        for (int k = (int)threadIdx.x; k < n * 12; k += kBlock) hot.mat[k / 12][k % 12] = g_inv[k];
         const double* __restrict__ src = reinterpret_cast<const double*>(g_shade);
         double* dst = reinterpret_cast<double*>(hot.shade);
         for (int k = (int)threadIdx.x; k < n * (int)(sizeof(DevShade) / 8); k += kBlock) dst[k] = src[k];
@@ -929,12 +930,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
         if constexpr (LDS)
             return hot.mat[i];
         else
-            return g_tab + (size_t)i * kRecDoubles;
+            return g_inv + (size_t)i * 12;
     };
-    const double* sweep_tab = g_tab;
-#ifdef RTC_LDS_SWEEP
-    if constexpr (LDS) sweep_tab = &hot.mat[0][0];
-#endif
+    const double* __restrict__ sweep_tab = g_tab;
     const int lane = (int)(threadIdx.x & 63);
     DevWorld w = wc;
     w.tab = g_tab;
@@ -1586,7 +1584,7 @@ hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t s
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.tab, world.shade, world.order, job.rays,
                        job.tile_order, job.out, job.counter, (unsigned long long*)job.stats, world.sphere_bounds_radiance,
-                       world.sphere_bounds_shadow, world, job);
+                       world.sphere_bounds_shadow, world.inv, world, job);
     return hipGetLastError();
 }
 
