@@ -130,6 +130,9 @@ typedef struct RtcStats {
     uint64_t plane_side_skips;
     uint64_t cube_tests; /* (ray, cube) pairs and those that produced t values (extension, RTC_GEO_CUBE) */
     uint64_t cube_hits;
+    /* (ray, sphere) pairs (part of sphere_tests) dismissed by the single-precision pre-test that runs ahead of
+     * the bounding test in worlds too large for the on-chip tables; they do not appear in sphere_bound_skips */
+    uint64_t sphere_prefilter_skips;
 } RtcStats;
 
 /* Opaque handle of an uploaded world (World, world.zig:15-28). */

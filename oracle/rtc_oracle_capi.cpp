@@ -74,6 +74,7 @@ void fillStats(const orc::Stats& s, RtcStats* out, uint64_t pixels, double ms) {
     out->plane_side_skips = 0;
     out->cube_tests = s.cube_tests;
     out->cube_hits = s.cube_hits;
+    out->sphere_prefilter_skips = 0;
 }
 
 }  // namespace

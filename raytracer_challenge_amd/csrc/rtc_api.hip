@@ -183,6 +183,8 @@ struct RtcScene {
     uint64_t n_spheres = 0, n_planes = 0, n_cubes = 0;
     double* d_tab = nullptr;
     double* d_inv = nullptr;            // rows 0..2 of inverse(shape.transform), 12 doubles per shape, table order
+    float* d_sphere_pairs = nullptr;    // single-precision pre-test tables: radiance, then shadow (see DevWorld)
+    size_t sphere_pairs_floats = 0;     // floats per table
     double* d_sphere_bounds = nullptr;  // radiance table, then shadow table (see DevWorld)
     size_t sphere_bounds_doubles = 0;   // doubles per table
     int32_t* d_order = nullptr;
@@ -234,6 +236,7 @@ void free_scene(RtcScene* s) {
     if (s->d_tab) (void)hipFree(s->d_tab);
     if (s->d_order) (void)hipFree(s->d_order);
     if (s->d_sphere_bounds) (void)hipFree(s->d_sphere_bounds);
+    if (s->d_sphere_pairs) (void)hipFree(s->d_sphere_pairs);
     if (s->d_inv) (void)hipFree(s->d_inv);
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_counter) (void)hipFree(s->d_counter);
@@ -252,6 +255,8 @@ rtc::DevWorld dev_world(const RtcScene* s) {
     w.tab = s->d_tab;
     w.order = s->d_order;
     w.inv = s->d_inv;
+    w.sphere_pairs_radiance = s->d_sphere_pairs;
+    w.sphere_pairs_shadow = s->d_sphere_pairs ? s->d_sphere_pairs + s->sphere_pairs_floats : nullptr;
     w.sphere_bounds_radiance = s->d_sphere_bounds;
     w.sphere_bounds_shadow = s->d_sphere_bounds ? s->d_sphere_bounds + s->sphere_bounds_doubles : nullptr;
     std::memcpy(w.group, s->group, sizeof w.group);
@@ -288,7 +293,7 @@ int check_camera(const RtcCameraDesc* c) {
 
 // Fill stats from the device counters (after the stream has been synchronised).
 int read_stats(RtcScene* s, const uint64_t* d_stats, RtcStats* out, uint64_t pixels, float ms) {
-    uint64_t h[8];
+    uint64_t h[9];
     HIP_TRY(hipMemcpy(h, d_stats, sizeof h, hipMemcpyDeviceToHost));
     out->radiance_rays = h[0];
     out->shadow_rays = h[1];
@@ -301,6 +306,7 @@ int read_stats(RtcScene* s, const uint64_t* d_stats, RtcStats* out, uint64_t pix
     out->plane_side_skips = h[6];
     out->cube_tests = (h[0] + h[1]) * s->n_cubes;
     out->cube_hits = h[7];
+    out->sphere_prefilter_skips = h[8];
     out->pixels = pixels;
     out->kernel_ms = ms;
     return RTC_OK;
@@ -690,6 +696,48 @@ void sphere_from_light(const double* bound, const double* light_pos, double out[
     out[3] = l2 * (1.0 - 0x1p-25) - bound[3] * (1.0 + 0x1p-40);
     if (!std::isfinite(out[0]) || !std::isfinite(out[1]) || !std::isfinite(out[2]) || !(out[3] == out[3]))
         out[3] = -std::numeric_limits<double>::infinity();
+}
+
+// Single-precision operands of the packed pre-test that runs ahead of the bounding tests in the streamed sweep
+// of large worlds (pair_clear, rtc_kernels.hip).  The pre-test may only dismiss a (ray, sphere) pair when the
+// double-precision test's inequality holds in exact arithmetic on the double operands,
+//     radiance:  (A - bound) D k > B^2        A = |c - o|^2, B = (c - o).d, D = |d|^2, k = 1 - 2^-27
+//     shadow:    lk - 2^-25 dist^2 > (lc.d)^2
+// so every rounding of the float evaluation has to be covered by margins (u = 2^-24):
+//  * c, o, d are rounded to float and c - o is rounded again: the computed difference vector is off by at most
+//    2.01 u s, s^2 = sum (|c_j| + |o_j|)^2 <= 2 (|c|^2 + |o|^2); its squared length, three more rounded
+//    operations, is off by at most 7.2 u s^2 < 2^-20 (|c|^2 + |o|^2); its product with d by beta = 6.1 u s |d|.
+//  * B^2 <= (1 + 2^-10) B~^2 + (1 + 2^10) beta^2, and the second term is below 2^-31 (|c|^2 + |o|^2) D k.
+//  * The two subtractions that form the left side add 4.1 u (|c|^2 + |o|^2).  In all at most
+//    2^-19.5 (|c|^2 + |o|^2) is lost on the left: the sphere's share, 2^-19.5 |c|^2, is added to its radius
+//    term here (rounded up), the ray's share is subtracted on the device (rounded up).
+//  * The factor 1 + 2^-10 and the rounding of the two final products are covered by scaling D k by 1 - 2^-9
+//    (rounded down) on the device.
+// Shadow rays: lc~.d~ is off by at most 5.2 u |lc| (|d| = 1 to 2^-50), so (lc.d)^2 <= (1 + 2^-10) (lc~.d~)^2 +
+// 2^-33 |lc|^2; the stored term is (lk - 2^-32 |lc|^2)(1 - 2^-8) rounded down, which also covers the rounding
+// of the device's subtraction and product; a term that is not positive can dismiss nothing (-inf).
+// Terms below 2^-100 are raised to it, so that flushed subnormals (at most 2^-126 per operation) stay covered;
+// an overflow gives an infinity or a NaN on the device, and a comparison with either dismisses nothing.
+float float_above(double v) {
+    float f = (float)v;
+    if (!((double)f >= v)) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+float float_below(double v) {
+    float f = (float)v;
+    if (!((double)f <= v)) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+void sphere_prefilter_tables(const double bound[4], const double from_light[4], float radiance[4], float shadow[4]) {
+    const float inf = std::numeric_limits<float>::infinity();
+    const double cc = bound[0] * bound[0] + bound[1] * bound[1] + bound[2] * bound[2];
+    for (int k = 0; k < 3; ++k) radiance[k] = (float)bound[k];
+    const double r = bound[3] + 0x1.6a09e667f3bcdp-20 * cc;  // 2^-19.5
+    radiance[3] = (std::isfinite(r) && std::isfinite(cc)) ? std::fmax(float_above(r), 0x1p-100f) : inf;  // +inf: never dismissed
+    const double ll = from_light[0] * from_light[0] + from_light[1] * from_light[1] + from_light[2] * from_light[2];
+    for (int k = 0; k < 3; ++k) shadow[k] = (float)from_light[k];
+    const double t = (from_light[3] - 0x1p-32 * ll) * (1.0 - 0x1p-8);
+    shadow[3] = (std::isfinite(t) && std::isfinite(ll) && t > 0x1p-100) ? float_below(t) : -inf;  // -inf: never dismissed
 }
 
 // Device canvas -> the caller's (pageable, usually freshly allocated) buffer.  A plain hipMemcpy
@@ -1129,6 +1177,26 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 side[(size_t)sb.pos * 4 + k] = sb.b[k];
                 side[sc->sphere_bounds_doubles + (size_t)sb.pos * 4 + k] = sb.from_light[k];
             }
+        // the packed pre-test's tables: 8 floats per pair of spheres; padding pairs dismiss (radius term -inf for
+        // radiance rays, +inf for shadow rays), real spheres without a bound never do
+        const size_t n_pairs = (n_sph + 1) / 2 + rtc::kSphereBoundsPadding;
+        sc->sphere_pairs_floats = n_pairs * 8;
+        std::vector<float> pairs(2 * sc->sphere_pairs_floats, 0.0f);
+        for (size_t q = 0; q < n_pairs; ++q) {
+            pairs[q * 8 + 6] = pairs[q * 8 + 7] = -std::numeric_limits<float>::infinity();
+            pairs[sc->sphere_pairs_floats + q * 8 + 6] = pairs[sc->sphere_pairs_floats + q * 8 + 7] = std::numeric_limits<float>::infinity();
+        }
+        for (const RtcScene::SphereBound& sb : sc->sphere_bounds) {
+            float rad[4], sha[4];
+            sphere_prefilter_tables(sb.b, sb.from_light, rad, sha);
+            const size_t q = (size_t)sb.pos / 2, half = (size_t)sb.pos % 2;
+            for (int k = 0; k < 4; ++k) {
+                pairs[q * 8 + 2 * k + half] = rad[k];
+                pairs[sc->sphere_pairs_floats + q * 8 + 2 * k + half] = sha[k];
+            }
+        }
+        SCENE_TRY(hipMalloc((void**)&sc->d_sphere_pairs, pairs.size() * sizeof(float)));
+        SCENE_TRY(hipMemcpy(sc->d_sphere_pairs, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));
         SCENE_TRY(hipMalloc((void**)&sc->d_sphere_bounds, side.size() * sizeof(double)));
         SCENE_TRY(hipMemcpy(sc->d_sphere_bounds, side.data(), side.size() * sizeof(double), hipMemcpyHostToDevice));
     }

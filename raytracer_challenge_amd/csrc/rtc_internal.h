@@ -17,14 +17,14 @@ constexpr int kMaxDepthLarge = 16;
 // Per-shape record read by one lane after it knows which shape it hit (a gather).
 // Everything a hit needs that the sweep table does not hold.
 // Per-scene control block in device memory: the heads of the work queues (one 128-byte line
-// each), then 64 bytes of statistics counters, then the developer probe area.
+// each), then 128 bytes of statistics counters, then the developer probe area.
 #ifndef RTC_QUEUES
 #define RTC_QUEUES 16
 #endif
 constexpr int kQueues = RTC_QUEUES;
 constexpr int kQueueStrideWords = 32;  // uint32 words between queue heads
 constexpr int kStatsOffsetBytes = kQueues * kQueueStrideWords * 4;
-constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 64;
+constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 128;
 
 // Layout of a sweep-table record (kRecordDoubles doubles) per group: every sweep reads a contiguous run.
 //   sphere with a diagonal inverse: [0..5] m0 m3 m5 m7 m10 m11, [6] list index, [7] bound radius term, [8..10] bound
@@ -121,6 +121,10 @@ struct DevWorld {
     // radiance rays [13..16] of the record, for shadow rays [20..23]; padded by kSphereBoundsPadding entries
     const double* sphere_bounds_radiance;
     const double* sphere_bounds_shadow;
+    // the same in single precision with widened margins, two spheres per record of 8 floats (x0 x1 y0 y1 z0 z1
+    // k0 k1), for the packed pre-test of the streamed sweep (sphere_prefilter_tables, rtc_api.hip)
+    const float* sphere_pairs_radiance;
+    const float* sphere_pairs_shadow;
     int32_t n;
     int32_t group[kSweepGroups + 1];
     // acceleration (rtc_scene_set_acceleration): nullptr = every sphere is tested (the reference's list walk)
@@ -154,7 +158,7 @@ struct DevJob {
     int32_t depth;
     double* out;
     uint32_t* counter;  // control block: the work-queue heads first, zeroed before the launch
-    uint64_t* stats;    // 8 counters (radiance, shadow, sphere hits, plane hits, shaded, sphere skips, plane skips, cube hits) or nullptr
+    uint64_t* stats;    // 9 counters (radiance, shadow, sphere hits, plane hits, shaded, sphere skips, plane skips, cube hits, prefilter skips) or nullptr
 };
 
 // Launchers implemented in rtc_kernels.hip.  grid_blocks == 0 lets the launcher size the

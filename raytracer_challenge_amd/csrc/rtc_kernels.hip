@@ -283,7 +283,7 @@ constexpr double kOnePlus = 1.0 + 0x1p-40;
 // STATS builds only: (ray, shape) pairs whose local intersect produced roots, and pairs the
 // bounding-sphere test dismissed.
 struct SweepCounters {
-    uint32_t sphere_hits, plane_hits, sphere_skips, plane_skips, cube_hits;
+    uint32_t sphere_hits, plane_hits, sphere_skips, plane_skips, cube_hits, sphere_prefilter_skips;
 };
 
 struct ShapeRec {
@@ -596,62 +596,128 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
 // whose latency is then exposed) only for a sphere some lane of the wave cannot dismiss.  Per sphere the
 // sweep moves 32 instead of 192 bytes from the L2 and issues a quarter of a load instruction instead of
 // three; what is evaluated, and in which order, is unchanged.
-struct Bounds4 {
-    double v[16];
+//
+// Ahead of that test runs the same test in packed single precision, two spheres per instruction: a third
+// pair of side tables holds, per pair of spheres, the centres and radius terms as floats.  It only ever
+// dismisses a pair: its margins cover every rounding of the float evaluation (derivation at
+// sphere_prefilter_tables, rtc_api.hip), so "clear" there implies the inequality the double test evaluates,
+// and a sphere it cannot dismiss goes on to the double test (operands fetched on demand) and from there as
+// before.  In a world of thousands of spheres nearly every pair ends in the float test: 7 instead of 13
+// vector instructions per radiance pair, 3.5 instead of 6 per shadow pair.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+struct Pairs4 {
+    float v[32];  // four pairs of spheres; per pair: cx0 cx1 cy0 cy1 cz0 cz1 r0 r1
 };
-__device__ __forceinline__ Bounds4 load_bounds4(const double* __restrict__ p) {
-    Bounds4 r;
+__device__ __forceinline__ Pairs4 load_pairs4(const float* __restrict__ p) {
+    Pairs4 r;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) r.v[k] = p[k];
+    for (int k = 0; k < 32; ++k) r.v[k] = p[k];
     return r;
 }
+// The ray in single precision, each component in both halves of a register pair.  Radiance rays: a = 2^-19.5
+// |o|^2 rounded up (the ray's share of the margin), b = |d|^2 (1 - 2^-27)(1 - 2^-9) rounded down.  Shadow
+// rays: a = 2^-25 dist^2 rounded up (the per-ray term of the light-anchored test).
+struct Ray32 {
+    float2_t ox, oy, oz, dx, dy, dz, a, b;
+};
+__device__ __forceinline__ float float_up(float x) { return __uint_as_float(__float_as_uint(x) + 1u); }    // x > 0
+__device__ __forceinline__ float float_down(float x) { return __uint_as_float(__float_as_uint(x) - 1u); }  // x > 0, normal
+template <bool SHADOW>
+__device__ __forceinline__ Ray32 ray_in_floats(const V3& o, const V3& d, double dd, double shadow_margin) {
+    Ray32 r;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    r.ox = {ox, ox}, r.oy = {oy, oy}, r.oz = {oz, oz}, r.dx = {dx, dx}, r.dy = {dy, dy}, r.dz = {dz, dz};
+    if (SHADOW) {
+        const float m = float_up(fmaxf((float)shadow_margin, 0x1p-100f));
+        r.a = {m, m};
+        r.b = {0.0f, 0.0f};
+    } else {
+        const double oo = fma(o.z, o.z, fma(o.y, o.y, o.x * o.x));
+        const float rho = float_up(fmaxf((float)(0x1.6a09e667f3bcdp-20 * oo), 0x1p-100f));
+        const float ds = (float)(dd * (1.0 - 0x1p-9));
+        const float dsd = ds > 0x1p-100f ? float_down(ds) : 0.0f;  // 0: nothing is dismissed for this ray
+        r.a = {rho, rho};
+        r.b = {dsd, dsd};
+    }
+    return r;
+}
+// two spheres against the ray: c0 / c1 = the pair's first / second sphere is certainly clear of the ray
+template <bool SHADOW>
+__device__ __forceinline__ void pair_clear(const float* __restrict__ p, const Ray32& r, bool& c0, bool& c1) {
+    const float2_t cx = {p[0], p[1]}, cy = {p[2], p[3]}, cz = {p[4], p[5]}, k = {p[6], p[7]};
+    float2_t lhs, rhs;
+    if (SHADOW) {
+        const float2_t lcd = __builtin_elementwise_fma(cz, r.dz, __builtin_elementwise_fma(cy, r.dy, cx * r.dx));
+        lhs = k - r.a;
+        rhs = lcd * lcd;
+    } else {
+        const float2_t x = cx - r.ox, y = cy - r.oy, z = cz - r.oz;
+        const float2_t oc2 = __builtin_elementwise_fma(z, z, __builtin_elementwise_fma(y, y, x * x));
+        const float2_t ocd = __builtin_elementwise_fma(z, r.dz, __builtin_elementwise_fma(y, r.dy, x * r.dx));
+        lhs = ((oc2 - r.a) - k) * r.b;
+        rhs = ocd * ocd;
+    }
+    c0 = lhs.x > rhs.x;
+    c1 = lhs.y > rhs.y;
+}
+
 template <bool SHADOW, bool STATS>
-__device__ __forceinline__ void sweep_spheres_streamed(const double* __restrict__ bounds, const double* __restrict__ tab,
-                                                       const int* __restrict__ order_of, int begin, int split, int end,
-                                                       const V3& o, const V3& d, double dd, double shadow_margin,
-                                                       Sweep& s, ContainerSlots& cs, SweepCounters& ctr) {
+__device__ __forceinline__ void sweep_spheres_streamed(const float* __restrict__ pairs, const double* __restrict__ bounds,
+                                                       const double* __restrict__ tab, const int* __restrict__ order_of,
+                                                       int begin, int split, int end, const V3& o, const V3& d, double dd,
+                                                       double shadow_margin, Sweep& s, ContainerSlots& cs,
+                                                       SweepCounters& ctr) {
     if (begin >= end) return;
-    // the full test of sphere i for the lanes whose bounding test did not dismiss it
-    auto full = [&](int i, bool clear) {
-        if (i < end && !clear) {  // (the tables are padded: the padding is not a shape)
-            if (i < split)  // the spheres with a diagonal inverse come first
-                sweep_shape<kSphereAxis, SHADOW, STATS, true>(load_rec<kSphereAxis, SHADOW>(tab, i), i, order_of, o, d, dd, 0.0,
-                                                              shadow_margin, s, cs, ctr);
-            else
-                sweep_shape<kSphereGeneral, SHADOW, STATS, true>(load_rec<kSphereGeneral, SHADOW>(tab, i), i, order_of, o, d, dd,
-                                                                 0.0, shadow_margin, s, cs, ctr);
+    const Ray32 r32 = ray_in_floats<SHADOW>(o, d, dd, shadow_margin);
+    // what the float test could not dismiss: the double test on the sphere's four operands (fetched now), then,
+    // for the lanes that fail it too, the full test on the sphere's record
+    auto rest = [&](int i, bool clear32) {
+        if (i >= end) return;  // (the tables are padded: the padding is not a shape)
+        if (STATS && clear32) ++ctr.sphere_prefilter_skips;
+        if (!clear32) {
+            const double* __restrict__ b = bounds + (size_t)i * 4;
+            const double bb[4] = {b[0], b[1], b[2], b[3]};
+            const bool clear = SHADOW ? sphere_clear_of_shadow_ray(bb, bb[3], d, shadow_margin)
+                                      : sphere_clear_of_ray(bb, bb[3], o, d, dd);
+            if (STATS && clear) ++ctr.sphere_skips;
+            if (!clear) {
+                if (i < split)  // the spheres with a diagonal inverse come first
+                    sweep_shape<kSphereAxis, SHADOW, STATS, true>(load_rec<kSphereAxis, SHADOW>(tab, i), i, order_of, o, d, dd,
+                                                                  0.0, shadow_margin, s, cs, ctr);
+                else
+                    sweep_shape<kSphereGeneral, SHADOW, STATS, true>(load_rec<kSphereGeneral, SHADOW>(tab, i), i, order_of, o,
+                                                                     d, dd, 0.0, shadow_margin, s, cs, ctr);
+            }
         }
     };
-    // four spheres: their bounding tests back to back (independent chains), one branch for the four
-    auto test = [&](const double* b) -> bool {
-        return SHADOW ? sphere_clear_of_shadow_ray(b, b[3], d, shadow_margin) : sphere_clear_of_ray(b, b[3], o, d, dd);
-    };
-    auto four = [&](const double* b, int i) {
-        // (four named flags, not an array: an array of flags is kept as bytes in a vector register and costs
-        // a handful of instructions per test to pack and unpack)
-        const bool c0 = test(b), c1 = test(b + 4), c2 = test(b + 8), c3 = test(b + 12);
-        if (STATS) {
-            if (c0 && i < end) ++ctr.sphere_skips;
-            if (c1 && i + 1 < end) ++ctr.sphere_skips;
-            if (c2 && i + 2 < end) ++ctr.sphere_skips;
-            if (c3 && i + 3 < end) ++ctr.sphere_skips;
-        }
-        if (!(c0 && c1 && c2 && c3)) {
-            full(i, c0);
-            full(i + 1, c1);
-            full(i + 2, c2);
-            full(i + 3, c3);
+    // eight spheres: four packed tests back to back, one branch for the eight (named flags: an array of
+    // flags would be kept as bytes in a vector register and cost instructions to pack and unpack)
+    auto eight = [&](const float* p, int i) {
+        bool c0, c1, c2, c3, c4, c5, c6, c7;
+        pair_clear<SHADOW>(p, r32, c0, c1);
+        pair_clear<SHADOW>(p + 8, r32, c2, c3);
+        pair_clear<SHADOW>(p + 16, r32, c4, c5);
+        pair_clear<SHADOW>(p + 24, r32, c6, c7);
+        if (STATS || !(c0 && c1 && c2 && c3 && c4 && c5 && c6 && c7)) {
+            rest(i, c0);
+            rest(i + 1, c1);
+            rest(i + 2, c2);
+            rest(i + 3, c3);
+            rest(i + 4, c4);
+            rest(i + 5, c5);
+            rest(i + 6, c6);
+            rest(i + 7, c7);
         }
     };
-    const double* __restrict__ p = bounds + (size_t)begin * 4;
-    Bounds4 A = load_bounds4(p);
-    for (int i = begin; i < end; i += 8, p += 32) {
-        asm volatile("" ::"s"(A.v[15]) : "memory");
-        const Bounds4 B = load_bounds4(p + 16);
-        four(A.v, i);
-        asm volatile("" ::"s"(B.v[15]) : "memory");
-        A = load_bounds4(p + 32);
-        four(B.v, i + 4);
+    const float* __restrict__ p = pairs + (size_t)begin * 4;
+    Pairs4 A = load_pairs4(p);
+    for (int i = begin; i < end; i += 16, p += 64) {
+        asm volatile("" ::"s"(A.v[31]) : "memory");
+        const Pairs4 B = load_pairs4(p + 32);
+        eight(A.v, i);
+        asm volatile("" ::"s"(B.v[31]) : "memory");
+        A = load_pairs4(p + 64);
+        eight(B.v, i + 8);
     }
 }
 
@@ -740,7 +806,8 @@ __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab
 // accepted (calc.zig:789: hit.t < distance); containers are not tracked.
 template <bool SHADOW, bool STATS, bool ACCEL, bool STREAM>
 __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, const int* __restrict__ order_of,
-                                            const double* __restrict__ sphere_bounds, const DevWorld& w, const V3& o,
+                                            const double* __restrict__ sphere_bounds,
+                                            const float* __restrict__ sphere_pairs, const DevWorld& w, const V3& o,
                                             const V3& d, Sweep& s, ContainerSlots& cs, SweepCounters& ctr) {
     const int tid = (int)threadIdx.x;
     // for the bounding-sphere tests: |d|^2, scaled by the shrink factor of the test (see sphere_clear_of_ray)
@@ -761,7 +828,7 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     if (ACCEL) {
         if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, shadow_margin, s, cs, ctr);
     } else if (STREAM) {
-        sweep_spheres_streamed<SHADOW, STATS>(sphere_bounds, tab, order_of, w.group[0], w.group[1], w.group[2], o, d, dd,
+        sweep_spheres_streamed<SHADOW, STATS>(sphere_pairs, sphere_bounds, tab, order_of, w.group[0], w.group[1], w.group[2], o, d, dd,
                                               shadow_margin, s, cs, ctr);
     } else {
         sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
@@ -866,9 +933,9 @@ static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
 // instruction (v_readlane) per 32 bits.  Reading them from the kernel-argument segment where
 // they are used costs a few scalar loads instead (the segment stays in the scalar cache); the
 // empty asm makes the address opaque, so that the loads are not hoisted out of the loop again.
-// Layout of the segment: the eleven pointers, then DevWorld, then DevJob (checked against the
+// Layout of the segment: the thirteen pointers, then DevWorld, then DevJob (checked against the
 // code object's metadata by the build's assembly listing).
-constexpr int kWorldArgOffset = 11 * 8;
+constexpr int kWorldArgOffset = 13 * 8;
 constexpr int kJobArgOffset = kWorldArgOffset + (int)sizeof(DevWorld);
 static_assert(sizeof(DevWorld) % 8 == 0 && alignof(DevJob) == 8 && alignof(DevWorld) == 8, "kernel-argument layout");
 typedef const __attribute__((address_space(4))) DevJob* JobArg;
@@ -903,7 +970,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                                                         unsigned long long* __restrict__ g_stats,
                                                         const double* __restrict__ g_bounds_r,
                                                         const double* __restrict__ g_bounds_s,
-                                                        const double* __restrict__ g_inv, const DevWorld wc,
+                                                        const double* __restrict__ g_inv,
+                                                        const float* __restrict__ g_pairs_r,
+                                                        const float* __restrict__ g_pairs_s, const DevWorld wc,
                                                         const DevJob job) {
     constexpr bool LDS = TABLES == 1;
     constexpr bool ACCEL = TABLES == 2;
@@ -1216,7 +1285,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
             const int remaining = ((aux >> kAuxRemShift) & 63) - sp;
             Sweep hit;
-            sweep_world<false, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_r, w, ro, rd, hit, containers, ctr);
+            sweep_world<false, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_r, g_pairs_r, w, ro, rd, hit, containers, ctr);
             RTC_STAMP(pc_sweep1);
 
             have_ret = true;
@@ -1277,7 +1346,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
                 Sweep sh_hit;
                 sh_hit.t = distance;
                 RTC_STAMP(pc_prep);
-                sweep_world<true, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_s, w, over_point, lightv, sh_hit, containers, ctr);
+                sweep_world<true, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_s, g_pairs_s, w, over_point, lightv, sh_hit, containers, ctr);
                 RTC_STAMP(pc_sweep2);
                 const bool in_shadow = sh_hit.idx >= 0;
 
@@ -1484,9 +1553,9 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 #endif
     if (STATS) {
         // one atomic per counter per wave
-        uint32_t v[8] = {n_radiance, n_shadow, ctr.sphere_hits, ctr.plane_hits, n_shaded, ctr.sphere_skips, ctr.plane_skips,
-                         ctr.cube_hits};
-        for (int c = 0; c < 8; ++c) {
+        uint32_t v[9] = {n_radiance, n_shadow, ctr.sphere_hits, ctr.plane_hits, n_shaded, ctr.sphere_skips, ctr.plane_skips,
+                         ctr.cube_hits, ctr.sphere_prefilter_skips};
+        for (int c = 0; c < 9; ++c) {
             unsigned long long sum = v[c];
             for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
             if (lane == 0) atomicAdd(&g_stats[c], sum);
@@ -1584,7 +1653,7 @@ hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t s
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, world.tab, world.shade, world.order, job.rays,
                        job.tile_order, job.out, job.counter, (unsigned long long*)job.stats, world.sphere_bounds_radiance,
-                       world.sphere_bounds_shadow, world.inv, world, job);
+                       world.sphere_bounds_shadow, world.inv, world.sphere_pairs_radiance, world.sphere_pairs_shadow, world, job);
     return hipGetLastError();
 }
 

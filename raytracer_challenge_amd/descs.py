@@ -106,6 +106,7 @@ class RtcStats(C.Structure):
         ("plane_side_skips", C.c_uint64),
         ("cube_tests", C.c_uint64),
         ("cube_hits", C.c_uint64),
+        ("sphere_prefilter_skips", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -332,6 +332,43 @@ def test_shadow_rays_that_graze_spheres(seed):
         assert_identical(sc.color_at(rays, 2), cpu, "shadow grazing, hierarchy")
 
 
+@pytest.mark.parametrize("seed", range(2))
+def test_grazing_rays_in_worlds_too_large_for_the_on_chip_tables(seed):
+    """Worlds of more than 32 shapes sweep their spheres through the streamed bounding tests: first a packed
+    single-precision test with widened margins, then the double-precision one, then the sphere's record.  The
+    grazing worlds (rays and shadow rays within 1e-15 ... 1e-6 of tangency on tiny, huge, far and stretched
+    spheres), enlarged by forty more spheres so that they take that path, must still give the literal
+    integrator's colours bit for bit, with and without the hierarchy."""
+    rng = np.random.default_rng(900 + seed)
+
+    def enlarge(w):
+        for _ in range(40):
+            r = float(10.0 ** rng.uniform(-3, 0.5))
+            c = rng.uniform(-30, 30, 3)
+            w.objects.append(Shape("sphere", Mat4.identity().scale(r, r * float(rng.uniform(0.5, 2)), r)
+                                   .translate(float(c[0]), float(c[1]), float(c[2])),
+                                   Material(color=Color(*rng.uniform(0, 1, 3)), reflective=float(rng.uniform(0, 0.5)))))
+        return w
+
+    w, rays = grazing_world_and_rays(seed)
+    enlarge(w)
+    assert len(w.objects) > 32
+    want = O.color_at(w, rays, 3, O.LITERAL)
+    with scene_of(w) as sc:
+        st = D.RtcStats()
+        assert_identical(sc.color_at(rays, 3, st), want, f"grazing rays, large world, seed {seed}")
+        assert st.sphere_prefilter_skips > 0 and st.sphere_bound_skips > 0
+        assert st.sphere_prefilter_skips + st.sphere_bound_skips < st.sphere_tests
+        assert_identical(sc.color_at(rays, 3), want, "same without statistics")
+        sc.set_acceleration(D.RTC_ACCEL_BVH)
+        assert_identical(sc.color_at(rays, 3), want, "same through the hierarchy")
+    w, rays = shadow_grazing_world_and_rays(seed)
+    enlarge(w)
+    cpu = O.color_at(w, rays, 2, O.STREAMING)
+    with scene_of(w) as sc:
+        assert_identical(sc.color_at(rays, 2), cpu, f"shadow grazing, large world, seed {seed}")
+
+
 def test_worlds_beyond_the_lds_table_size_and_one_kind_worlds():
     """More than 32 shapes: what a hit gathers comes from global memory instead of the LDS copy;
     worlds of spheres only / planes only leave sweep groups empty."""
