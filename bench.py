@@ -65,16 +65,19 @@ def executed_flops(st, groups, table):
     30 instead of 54 per ray-sphere test, 3 instead of 11 per ray-plane test; every ray-sphere
     pair first pays 17 flops for the bounding-sphere test (5 more per sweep), and the pairs it
     dismisses pay nothing else (the dismissed pairs are taken as spread evenly over the sphere
-    groups); a plane that a shadow ray's origin shares a side of with the light costs its origin
+    groups); in a world too large for the on-chip tables a single-precision pre-test runs ahead of
+    that test, and the pairs it dismisses (sphere_prefilter_skips) pay no double-precision flop
+    at all (its own single-precision operations are not counted: the peak is an FP64 peak); a plane that a shadow ray's origin shares a side of with the light costs its origin
     row only (2 of 3, or 6 of 11 flops; taken as spread evenly over the plane groups).  Root
     filters and bookkeeping compares are not counted."""
     rays = st["radiance_rays"] + st["shadow_rays"]
-    kept = 1.0 - st["sphere_bound_skips"] / max(st["sphere_tests"], 1)
+    pre = st.get("sphere_prefilter_skips", 0) / max(st["sphere_tests"], 1)
+    kept = 1.0 - pre - st["sphere_bound_skips"] / max(st["sphere_tests"], 1)
     side = st["plane_side_skips"] / max(st["plane_tests"], 1)
     per_ray = 5.0
     for n, g in zip(groups, table):
         if g["geo"] == 0:  # RTC_GEO_SPHERE
-            per_ray += n * (17 + kept * g["flops_executed"])
+            per_ray += n * (17 * (1.0 - pre) + kept * g["flops_executed"])
         elif g["geo"] == 1:  # RTC_GEO_PLANE: the direction row is 1 of 3, or 5 of 11 flops
             per_ray += n * (g["flops_executed"] - side * (1 if g["axis_aligned"] else 5))
         else:
@@ -352,13 +355,14 @@ def main():
     scene.render_device(cam, args.depth, local.data_ptr(), rank, world_size, stream, st)
     counts = torch.tensor(
         [st.radiance_rays, st.shadow_rays, st.sphere_tests, st.plane_tests, st.sphere_hits, st.plane_hits,
-         st.shaded_hits, st.sphere_bound_skips, st.plane_side_skips],
+         st.shaded_hits, st.sphere_bound_skips, st.plane_side_skips, st.cube_tests, st.cube_hits,
+         st.sphere_prefilter_skips],
         dtype=torch.int64, device=dev,
     )
     if world_size > 1:
         dist.all_reduce(counts)
     names = ["radiance_rays", "shadow_rays", "sphere_tests", "plane_tests", "sphere_hits", "plane_hits", "shaded_hits",
-             "sphere_bound_skips", "plane_side_skips"]
+             "sphere_bound_skips", "plane_side_skips", "cube_tests", "cube_hits", "sphere_prefilter_skips"]
     total = dict(zip(names, (int(v) for v in counts.tolist())))
     group_table = native.sweep_group_table()
     local_flops = algorithmic_flops(st.as_dict(), scene.group_counts(), group_table)
@@ -510,6 +514,26 @@ def main():
                 "instruction for the issue fraction, FMA twice for the flop comparison. The counters also "
                 "see division, sqrt and pow expansions, which the model prices at one flop each",
             }
+        if st.sphere_prefilter_skips:
+            # a world too large for the on-chip tables: nearly every ray-sphere pair ends in the packed
+            # single-precision pre-test, which the FP64 figures above do not see.  Per pair it costs 17
+            # single-precision flops for a radiance ray (difference 3, two dot products 5 + 5, margin 2,
+            # two products 2) and 7 for a shadow ray (dot product 5, margin 1, square 1).
+            groups_now = scene.group_counts()
+            n_sph = sum(n for n, g in zip(groups_now, group_table) if g["geo"] == 0)
+            f32 = (st.radiance_rays * 17 + st.shadow_rays * 7) * n_sph
+            roofline["bound"] = "valu-issue (packed f32 pre-test + f64)"
+            roofline["f32_prefilter_flops_per_launch"] = f32
+            roofline["f32_prefilter_achieved_tflops"] = f32 / sec / 1e12
+            roofline["f32_packed_peak_tflops_no_fma"] = 2 * PEAK_FP64_NO_FMA_TFLOPS
+            roofline["pairs_dismissed_by_f32_pre_test"] = st.sphere_prefilter_skips / max(st.sphere_tests, 1)
+            roofline["note"] += (". In this workload the single-precision pre-test dismisses most ray-sphere pairs "
+                                 "before any FP64 operation: `frac` (FP64 flops only) is then no measure of how busy "
+                                 "the vector units are; `counter_check.valu_busy` is")
+            if "counter_check" in roofline:
+                # the few lanes that go on to the double test run it with most of the wave masked off, so
+                # wave-instructions x average lanes over-states the FP64 lane operations
+                roofline["counter_check"]["model_over_lane_flops"] = None
         out = {
             "metric": "rays/sec (primary+secondary) at 3840x2160 depth 5" if args.workload == "c3"
             else f"rays/sec (primary+secondary), workload {args.workload}",

@@ -260,6 +260,9 @@ int render_frame(RtcMulti* m, const RtcCameraDesc* cam, int32_t depth, int32_t m
         total.shaded_hits += s.shaded_hits;
         total.sphere_bound_skips += s.sphere_bound_skips;
         total.plane_side_skips += s.plane_side_skips;
+        total.cube_tests += s.cube_tests;
+        total.cube_hits += s.cube_hits;
+        total.sphere_prefilter_skips += s.sphere_prefilter_skips;
         total.kernel_ms = s.kernel_ms > total.kernel_ms ? s.kernel_ms : total.kernel_ms;
     };
 
