@@ -469,7 +469,8 @@ def main():
         achieved = local_executed / sec / 1e12
         achieved_alg = local_flops / sec / 1e12
         frac_alg = achieved_alg / PEAK_FP64_NO_FMA_TFLOPS
-        pmc = pmc_counters(args.workload, world_size)
+        # (the committed counter passes are of the default command: depth 5, list walk)
+        pmc = pmc_counters(args.workload, world_size) if args.depth == 5 and not args.accel else None
         roofline = {
             "bound": "fp64-valu",
             "achieved": achieved,

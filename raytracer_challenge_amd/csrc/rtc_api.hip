@@ -1059,7 +1059,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     }
 
     std::vector<RtcScene::SphereBound> bounds;
-    // table order: the four groups one after the other, each in list order
+    // table order: the groups one after the other, each in list order
     std::vector<double> tab((n_shapes + 2) * kRec, 0.0);
     std::vector<double> inv_tab((n_shapes ? n_shapes : 1) * 12, 0.0);  // rows 0..2 of every inverse, table order (gathers)
     std::vector<int32_t> order(n_shapes ? n_shapes : 1, 0);

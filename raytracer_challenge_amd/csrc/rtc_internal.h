@@ -87,8 +87,8 @@ struct DevShade {
 // Device-side view of an uploaded world.
 //
 // Layout in HBM (all allocated once per scene, read-only while rendering):
-// The shapes are stored in "table order": four groups (spheres whose inverse is diagonal,
-// other spheres, planes whose inverse row 1 is (0,m,0,t), other planes), each group in the
+// The shapes are stored in "table order": five groups (spheres whose inverse is diagonal,
+// other spheres, planes whose inverse row 1 is (0,m,0,t), other planes, cubes), each group in the
 // reference's list order.  group[g]..group[g+1] are the table positions of group g.
 //   tab   : (n+2) x 24 doubles, one 192-byte record per shape, laid out per group (kRec* above) so that what
 //           a sweep reads of it is one contiguous run: the entries of rows 0..2 of inverse(shape.transform)

@@ -347,7 +347,7 @@ struct ContainerSlots {
     int i[2][kBlock];
 };
 
-// The table holds the shapes in four groups, each in list order, so that each group is
+// The table holds the shapes in groups (kSweepGroupTable), each in list order, so that each group is
 // swept by a loop specialised for it: no per-shape dispatch, and the zero entries of
 // axis-aligned inverses are never multiplied.
 static_assert(kSweepGroupTable[kSphereAxis].geo == RTC_GEO_SPHERE && kSweepGroupTable[kSphereAxis].axis_aligned &&
