@@ -136,6 +136,19 @@ def single_process_multi(native, D, world, cam, args, hsize, vsize):
                 res[name] = {"frame_ms": dt * 1e3, "identical_to_rtc_render": same, "last_call": tm.as_dict()}
             except native.RtcError as e:
                 res[name] = {"error": str(e)}
+        # with the canvas delivered to the caller's host buffer: rank 0's GPU copying the assembled canvas out
+        # (one PCIe link) against every rank scattering its tiles into pinned host memory over its own link
+        for name, mode in (("peer_stores_to_host", D.RTC_MULTI_PEER_STORES), ("host_direct_to_host", D.RTC_MULTI_HOST_DIRECT)):
+            try:
+                same = bool(np.array_equal(m.render(cam, args.depth, mode), want))
+                tm = D.RtcMultiTiming()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    m.render(cam, args.depth, mode, None, tm)
+                dt = (time.perf_counter() - t0) / args.steps
+                res[name] = {"frame_ms": dt * 1e3, "identical_to_rtc_render": same, "last_call": tm.as_dict()}
+            except native.RtcError as e:
+                res[name] = {"error": str(e)}
     return res
 
 
@@ -223,6 +236,7 @@ def main():
                     "every transfer mode; reported under config.single_process_multi, never as `value`")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -307,6 +321,29 @@ def main():
             peer_canvas_usable = False
         else:
             peer_canvas_usable = True
+    # fourth leg for N > 1: no GPU-to-GPU traffic at all.  Every rank copies its dense tile buffer to pinned
+    # host memory of its own over its GPU's own PCIe link; the tiles of the frame then lie in N host buffers
+    # (in one process, rtc_render_multi's RTC_MULTI_HOST_DIRECT scatters them into one host canvas instead).
+    local_host = None
+    host_why = None
+    if world_size > 1:
+        try:
+            local_host = torch.empty(n_local, dtype=torch.float64, pin_memory=True)
+        except Exception as e:  # no pinned memory to be had: the leg is reported as unavailable
+            host_why = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([1 if local_host is not None else 0], dtype=torch.int32,
+                          device="cpu" if args.rehearse_on_one_gpu else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            local_host = None
+            host_why = host_why or "another rank could not allocate pinned host memory"
+
+    def render_and_copy_to_own_host_buffer():
+        scene.render_device(cam, args.depth, local.data_ptr(), rank, world_size, stream)
+        local_host.copy_(local[:n_local], non_blocking=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+
     sync_token = torch.zeros(1, dtype=torch.int32, device=dev) if world_size > 1 else None
 
     def render_into_peer_canvas():
@@ -414,7 +451,27 @@ def main():
         fence()
         elapsed_peer = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed, kernel_ms, elapsed_u8, elapsed_peer], dtype=torch.float64, device=dev)
+    elapsed_host = 0.0
+    if world_size > 1 and local_host is not None:
+        for _ in range(max(args.warmup, 1)):
+            render_and_copy_to_own_host_buffer()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            render_and_copy_to_own_host_buffer()
+        fence()
+        elapsed_host = time.perf_counter() - t0
+        # what arrived in the host buffers goes through the (already verified) gather once more, outside the
+        # timed region, and is compared with the 1-rank render below
+        local[:n_local].copy_(local_host)
+        gather_and_assemble()
+        fence()
+        host_canvas_copy = canvas.clone() if rank == 0 else None
+        # (and the canvas of the headline leg is put back)
+        step()
+        fence()
+
+    t = torch.tensor([elapsed, kernel_ms, elapsed_u8, elapsed_peer, elapsed_host], dtype=torch.float64, device=dev)
     if world_size > 1:
         if args.rehearse_on_one_gpu:
             tc = t.cpu()
@@ -422,16 +479,18 @@ def main():
             t = tc
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max, kernel_ms_max, elapsed_u8_max, elapsed_peer_max = (float(v) for v in t.tolist())
+    elapsed_max, kernel_ms_max, elapsed_u8_max, elapsed_peer_max, elapsed_host_max = (float(v) for v in t.tolist())
 
     # Every N > 1 run checks what it assembled: rank 0 renders the whole frame alone (outside the timed
     # regions) and compares the canvases value for value.  A leg that differs is not reported.
-    gather_ok = peer_ok = None
+    gather_ok = peer_ok = host_ok = None
     if world_size > 1 and rank == 0:
         whole = torch.empty(hsize * vsize * 3, dtype=torch.float64, device=dev)
         scene.render_device(cam, args.depth, whole.data_ptr(), 0, 1, stream)
         torch.cuda.synchronize()
         gather_ok = bool(torch.equal(whole, canvas))
+        if local_host is not None:
+            host_ok = bool(torch.equal(whole, host_canvas_copy))
         if peer_canvas_usable:
             peer_t = _device_view(torch, peer_canvas, hsize * vsize * 3, dev)
             peer_ok = bool(torch.equal(whole, peer_t))
@@ -442,10 +501,11 @@ def main():
         torch.cuda.synchronize()
         u8_ok = bool(torch.equal(q, canvas_u8))
         if args.verify:
-            if not (gather_ok and u8_ok and peer_ok is not False):
-                raise SystemExit(f"verify FAILED: gather {gather_ok}, 8-bit gather {u8_ok}, peer stores {peer_ok}")
+            if not (gather_ok and u8_ok and peer_ok is not False and host_ok is not False):
+                raise SystemExit(f"verify FAILED: gather {gather_ok}, 8-bit gather {u8_ok}, peer stores {peer_ok}, "
+                                 f"own D2H {host_ok}")
             print(f"verify ok: assembled canvases identical to the 1-rank render (f64 gather, 8-bit gather, "
-                  f"peer stores: {peer_ok})", file=sys.stderr)
+                  f"peer stores: {peer_ok}, own D2H: {host_ok})", file=sys.stderr)
 
     if rank == 0:
         ms_gather = elapsed_max * 1e3 / args.steps
@@ -577,8 +637,13 @@ def main():
             out["config"]["rays_per_s_with_u8_gather"] = total["radiance_rays"] / (ms_u8 * 1e-3) if u8_ok else None
             out["config"]["frame_ms_with_peer_stores"] = ms_peer
             out["config"]["peer_stores_unavailable_because"] = peer_why
+            # every GPU copying its own tiles to pinned host memory, no gather (never the headline: the other legs
+            # leave the canvas on rank 0's GPU, this one ends in N host buffers and includes the trip over PCIe)
+            out["config"]["frame_ms_with_own_d2h_no_gather"] = (
+                elapsed_host_max * 1e3 / args.steps if (local_host is not None and host_ok) else None)
+            out["config"]["own_d2h_unavailable_because"] = host_why
             out["config"]["canvases_verified_against_1_rank_render"] = {"f64_gather": gather_ok, "u8_gather": u8_ok,
-                                                                        "peer_stores": peer_ok}
+                                                                        "peer_stores": peer_ok, "own_d2h": host_ok}
         if world_size == 1 and args.multi_ranks > 0:
             out["config"]["single_process_multi"] = single_process_multi(native, D, world, cam, args, hsize, vsize)
         if world_size == 1 and not args.no_cpu_baseline:

@@ -319,6 +319,14 @@ int rtc_multi_rank_device(const RtcMulti* multi, uint32_t rank, int32_t* out_dev
                                     quantising, so 3 instead of 24 bytes per pixel cross the link) */
 #define RTC_MULTI_RCCL_GATHER 2  /* dense tile buffers, RCCL send/recv to rank 0 (single process,
                                     ncclCommInitAll), de-interleave kernel on rank 0 */
+#define RTC_MULTI_HOST_DIRECT 3  /* dense tile buffers; each rank scatters its tiles over its own PCIe link
+                                    into a pinned host canvas kept by the library, which host threads then
+                                    move into the caller's buffer: nothing crosses between the GPUs, rank 0
+                                    assembles nothing, and the copy to the host is split over the ranks'
+                                    links.  The destination must not be NULL; with one rank the frame is
+                                    rendered and copied as by rtc_render.  In RtcMultiTiming the transfer to
+                                    the pinned canvas counts as render_and_transfer_ms, the host threads'
+                                    copy as to_host_ms */
 
 /* Device-side phases of one call, in milliseconds: from the first launch until every rank's pixels
  * are on rank 0's GPU (rendering and the transfers, which overlap in the peer modes), then rank

@@ -33,6 +33,9 @@ int fail(int code, const std::string& msg) {
 
 int fail_hip(const char* what, hipError_t e) {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    // the failure is reported through the status code; the runtime's own sticky "last error" is cleared, so
+    // that it does not resurface in the caller's next, unrelated HIP call (a framework checking hipGetLastError)
+    (void)hipGetLastError();
     return e == hipErrorOutOfMemory ? RTC_ERR_OUT_OF_MEMORY : RTC_ERR_DEVICE;
 }
 

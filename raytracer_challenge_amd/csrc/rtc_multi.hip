@@ -13,6 +13,10 @@
 //                           tiles into rank 0's canvas through peer access in long runs
 //   RTC_MULTI_RCCL_GATHER   dense tile buffers, RCCL send/recv to rank 0 (ncclCommInitAll, one
 //                           communicator rank per GPU), de-interleave kernel on rank 0
+//   RTC_MULTI_HOST_DIRECT   dense tile buffers; each rank's scatter kernel writes its tiles at their final
+//                           place in a pinned host canvas over that GPU's own PCIe link: nothing crosses
+//                           between the GPUs, rank 0 assembles nothing, and the copy to the host, the
+//                           bottleneck of a one-GPU frame, is split N ways
 // One host thread drives every GPU: all launches are asynchronous, each rank has its own stream,
 // and rank 0's stream waits on an event per rank before the canvas is used.
 #include "rtc_internal.h"
@@ -25,7 +29,9 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -103,6 +109,9 @@ struct RtcMulti {
     size_t gathered_doubles = 0;
     uint8_t* gathered_u8 = nullptr;
     size_t gathered_u8_bytes = 0;
+    // host-direct mode: the pinned host canvas (f64 or 8-bit, whichever the frame asks for)
+    void* h_canvas = nullptr;
+    size_t h_canvas_bytes = 0;
     hipEvent_t t_begin = nullptr, t_rendered = nullptr, t_end = nullptr;
     // RCCL: one communicator rank per distinct GPU, in order of first appearance among the ranks
     std::vector<int> comm_device;
@@ -143,6 +152,7 @@ void destroy_multi(RtcMulti* m) {
     if (m->canvas_u8) (void)hipFree(m->canvas_u8);
     if (m->gathered) (void)hipFree(m->gathered);
     if (m->gathered_u8) (void)hipFree(m->gathered_u8);
+    if (m->h_canvas) (void)hipHostFree(m->h_canvas);
     for (hipEvent_t e : {m->t_begin, m->t_rendered, m->t_end})
         if (e) (void)hipEventDestroy(e);
     delete m;
@@ -184,9 +194,13 @@ uint64_t doubles_of_rank(const RtcCameraDesc* cam, uint32_t rank, uint32_t ranks
 // every stream still running; m->t_end is recorded on rank 0's stream behind the last operation.
 int render_frame(RtcMulti* m, const RtcCameraDesc* cam, int32_t depth, int32_t mode, bool want_u8, RtcStats* stats) {
     const uint32_t R = m->ranks;
-    if (mode != RTC_MULTI_PEER_STORES && mode != RTC_MULTI_PEER_SCATTER && mode != RTC_MULTI_RCCL_GATHER)
+    if (mode != RTC_MULTI_PEER_STORES && mode != RTC_MULTI_PEER_SCATTER && mode != RTC_MULTI_RCCL_GATHER &&
+        mode != RTC_MULTI_HOST_DIRECT)
         return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "unknown multi-GPU mode");
-    if (mode != RTC_MULTI_RCCL_GATHER && !m->peer_ok) {
+    // one rank: the canvas is rendered where rtc_render renders it, and copied like there
+    const bool host_direct = mode == RTC_MULTI_HOST_DIRECT && R > 1;
+    if (mode == RTC_MULTI_HOST_DIRECT && R == 1) mode = RTC_MULTI_PEER_STORES;
+    if ((mode == RTC_MULTI_PEER_STORES || mode == RTC_MULTI_PEER_SCATTER) && !m->peer_ok) {
         const std::string msg = "peer access to rank 0's GPU is not available (" + m->peer_why + "): use RTC_MULTI_RCCL_GATHER";
         return rtc::set_error(RTC_ERR_DEVICE, msg.c_str());
     }
@@ -196,8 +210,20 @@ int render_frame(RtcMulti* m, const RtcCameraDesc* cam, int32_t depth, int32_t m
     const size_t values = (size_t)cam->hsize * cam->vsize * 3;
 
     MULTI_HIP(hipSetDevice(m->device[0]));
-    // with 8-bit output and per-rank quantisation the f64 canvas is not needed on rank 0
-    const bool f64_canvas = !(want_u8 && tiled);
+    // with 8-bit output and per-rank quantisation the f64 canvas is not needed on rank 0; in
+    // host-direct mode no canvas is
+    const bool f64_canvas = !(want_u8 && tiled) && !host_direct;
+    if (host_direct) {
+        const size_t need = want_u8 ? values : values * sizeof(double);
+        if (m->h_canvas_bytes < need) {
+            if (m->h_canvas) (void)hipHostFree(m->h_canvas);
+            m->h_canvas = nullptr;
+            m->h_canvas_bytes = 0;
+            // portable + mapped: every rank's GPU addresses it (through the same pointer: unified addressing)
+            MULTI_HIP(hipHostMalloc(&m->h_canvas, need, hipHostMallocPortable | hipHostMallocMapped));
+            m->h_canvas_bytes = need;
+        }
+    }
     if (f64_canvas) {
         void* p = m->canvas;
         size_t have = m->canvas_doubles * sizeof(double);
@@ -205,7 +231,7 @@ int render_frame(RtcMulti* m, const RtcCameraDesc* cam, int32_t depth, int32_t m
         m->canvas = (double*)p;
         m->canvas_doubles = have / sizeof(double);
     }
-    if (want_u8) {
+    if (want_u8 && !host_direct) {
         void* p = m->canvas_u8;
         MULTI_RTC(ensure_device_buffer(&p, &m->canvas_u8_bytes, values));
         m->canvas_u8 = (uint8_t*)p;
@@ -282,15 +308,17 @@ int render_frame(RtcMulti* m, const RtcCameraDesc* cam, int32_t depth, int32_t m
         if (stats) add_stats(s);
     }
 
-    // ---- bring the tiles to rank 0 ----------------------------------------------------------------
-    if (tiled && mode == RTC_MULTI_PEER_SCATTER) {
+    // ---- bring the tiles to rank 0 (or, host-direct, to the pinned host canvas) ----------------------
+    if (tiled && (mode == RTC_MULTI_PEER_SCATTER || host_direct)) {
         for (uint32_t r = 0; r < R; ++r) {
             MULTI_HIP(hipSetDevice(m->device[r]));
+            void* target = host_direct ? nullptr : (want_u8 ? (void*)m->canvas_u8 : (void*)m->canvas);
+            if (host_direct) MULTI_HIP(hipHostGetDevicePointer(&target, m->h_canvas, 0));
             if (want_u8) {
                 MULTI_RTC(rtc_quantize_u8_device(m->tiles[r], doubles_of_rank(cam, r, R), m->tiles_u8[r], m->stream[r]));
-                MULTI_RTC(rtc_scatter_tiles_u8_device(cam, r, R, m->tiles_u8[r], m->canvas_u8, m->stream[r]));
+                MULTI_RTC(rtc_scatter_tiles_u8_device(cam, r, R, m->tiles_u8[r], target, m->stream[r]));
             } else {
-                MULTI_RTC(rtc_scatter_tiles_device(cam, r, R, m->tiles[r], m->canvas, m->stream[r]));
+                MULTI_RTC(rtc_scatter_tiles_device(cam, r, R, m->tiles[r], target, m->stream[r]));
             }
         }
     }
@@ -467,7 +495,28 @@ static int finish_frame(RtcMulti* m, RtcMultiTiming* timing, std::chrono::steady
     MULTI_HIP(hipSetDevice(m->device[0]));
     MULTI_HIP(hipEventSynchronize(m->t_end));
     const auto t1 = std::chrono::steady_clock::now();
-    if (dst) MULTI_RTC(rtc::copy_device_to_host(m->scene[0], d_src, dst, bytes));
+    if (dst && d_src == nullptr) {
+        // host-direct: the frame lies in the library's pinned canvas; a few threads move it on (the caller's
+        // buffer is usually fresh pageable memory, whose first touch is what takes the time)
+        const size_t kSlice = 8u << 20;
+        const size_t n_slices = (bytes + kSlice - 1) / kSlice;
+        std::atomic<size_t> next{0};
+        auto mover = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= n_slices) return;
+                const size_t begin = k * kSlice, len = bytes - begin < kSlice ? bytes - begin : kSlice;
+                std::memcpy((char*)dst + begin, (const char*)m->h_canvas + begin, len);
+            }
+        };
+        std::vector<std::thread> helpers;
+        const size_t n_helpers = n_slices > 1 ? (n_slices - 1 < 7 ? n_slices - 1 : 7) : 0;
+        for (size_t t = 0; t < n_helpers; ++t) helpers.emplace_back(mover);
+        mover();
+        for (std::thread& t : helpers) t.join();
+    } else if (dst) {
+        MULTI_RTC(rtc::copy_device_to_host(m->scene[0], d_src, dst, bytes));
+    }
     const auto t2 = std::chrono::steady_clock::now();
     if (timing) {
         float a = 0, b = 0;
@@ -527,9 +576,13 @@ int rtc_render_multi(RtcMulti* multi, const RtcCameraDesc* camera, int32_t depth
     int previous = 0;
     MULTI_HIP(hipGetDevice(&previous));
     const auto t0 = std::chrono::steady_clock::now();
+    const bool host_direct = mode == RTC_MULTI_HOST_DIRECT && multi->ranks > 1;
+    if (host_direct && !out_rgb)
+        return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "RTC_MULTI_HOST_DIRECT assembles the canvas in host memory: out_rgb is NULL");
     int rc = render_frame(multi, camera, depth, mode, false, stats);
     if (rc == RTC_OK)
-        rc = finish_frame(multi, timing, t0, out_rgb, multi->canvas, (size_t)camera->hsize * camera->vsize * 3 * sizeof(double));
+        rc = finish_frame(multi, timing, t0, out_rgb, host_direct ? nullptr : multi->canvas,
+                          (size_t)camera->hsize * camera->vsize * 3 * sizeof(double));
     (void)hipSetDevice(previous);
     return rc;
 }
@@ -541,8 +594,13 @@ int rtc_render_multi_u8(RtcMulti* multi, const RtcCameraDesc* camera, int32_t de
     int previous = 0;
     MULTI_HIP(hipGetDevice(&previous));
     const auto t0 = std::chrono::steady_clock::now();
+    const bool host_direct = mode == RTC_MULTI_HOST_DIRECT && multi->ranks > 1;
+    if (host_direct && !out_rgb8)
+        return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "RTC_MULTI_HOST_DIRECT assembles the canvas in host memory: out_rgb8 is NULL");
     int rc = render_frame(multi, camera, depth, mode, true, stats);
-    if (rc == RTC_OK) rc = finish_frame(multi, timing, t0, out_rgb8, multi->canvas_u8, (size_t)camera->hsize * camera->vsize * 3);
+    if (rc == RTC_OK)
+        rc = finish_frame(multi, timing, t0, out_rgb8, host_direct ? nullptr : multi->canvas_u8,
+                          (size_t)camera->hsize * camera->vsize * 3);
     (void)hipSetDevice(previous);
     return rc;
 }

@@ -33,6 +33,7 @@ RTC_IPC_HANDLE_BYTES = 64
 RTC_MULTI_PEER_STORES = 0
 RTC_MULTI_PEER_SCATTER = 1
 RTC_MULTI_RCCL_GATHER = 2
+RTC_MULTI_HOST_DIRECT = 3
 RTC_TILE_W = 64
 RTC_TILE_H = 8
 

@@ -14,7 +14,7 @@ from raytracer_challenge_amd import byte_color_values, descs as D, native, scene
 
 pytestmark = pytest.mark.gpu
 
-MODES = (D.RTC_MULTI_PEER_STORES, D.RTC_MULTI_PEER_SCATTER, D.RTC_MULTI_RCCL_GATHER)
+MODES = (D.RTC_MULTI_PEER_STORES, D.RTC_MULTI_PEER_SCATTER, D.RTC_MULTI_RCCL_GATHER, D.RTC_MULTI_HOST_DIRECT)
 
 
 def _multi(world, ranks, devices=None):
@@ -97,6 +97,13 @@ def test_render_multi_argument_errors():
         with pytest.raises(native.RtcError) as e:
             m.render(c.desc(), 17, D.RTC_MULTI_PEER_STORES)
         assert e.value.code == D.RTC_ERR_TOO_LARGE
+        # the host-direct mode assembles the canvas in host memory: it has nothing to leave on a GPU
+        with pytest.raises(native.RtcError) as e:
+            m.render(c.desc(), 5, D.RTC_MULTI_HOST_DIRECT, to_host=False)
+        assert e.value.code == D.RTC_ERR_INVALID_ARGUMENT
+        with pytest.raises(native.RtcError) as e:
+            m.render_u8(c.desc(), 5, D.RTC_MULTI_HOST_DIRECT, to_host=False)
+        assert e.value.code == D.RTC_ERR_INVALID_ARGUMENT
         assert m.render(c.desc(), 5).shape == (32, 64, 3)
 
 
@@ -133,8 +140,9 @@ def test_to_canvas_and_scatter_entry_points():
 def test_one_process_per_rank_front_end_with_ipc_canvas():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here
     with two ranks that share the one GPU and a gloo gather through the host: the f64 gather, the 8-bit
-    gather and the peer-store leg (rank 0's canvas mapped into rank 1 with rtc_ipc_canvas_create/open,
-    rtc_render_device_to_canvas from both processes) must all reproduce the 1-rank canvas."""
+    gather, the peer-store leg (rank 0's canvas mapped into rank 1 with rtc_ipc_canvas_create/open,
+    rtc_render_device_to_canvas from both processes) and the leg without a gather (every rank copies its tiles to pinned host
+    memory of its own) must all reproduce the 1-rank canvas."""
     import json
     import os
     import subprocess
@@ -152,4 +160,4 @@ def test_one_process_per_rank_front_end_with_ipc_canvas():
     out = json.loads(line)
     assert out["n_gpus"] == 2
     assert out["config"]["canvases_verified_against_1_rank_render"] == {"f64_gather": True, "u8_gather": True,
-                                                                        "peer_stores": True}
+                                                                        "peer_stores": True, "own_d2h": True}
