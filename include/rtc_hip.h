@@ -169,6 +169,21 @@ int rtc_scene_destroy(RtcScene* scene);
 #define RTC_ACCEL_BVH 1
 int rtc_scene_set_acceleration(RtcScene* scene, int32_t mode);
 
+/* How a pixel's tree of reflected and refracted rays (calc.shadeHit, calc.zig:460-469) is summed.
+ * RTC_INTEGRATOR_POSTORDER (the default) evaluates the reference's expressions in the reference's
+ * order, surface.add(reflected.scale(..)).add(refracted.scale(..)) from the leaves up: the canvas is
+ * the reference's value for value.  RTC_INTEGRATOR_WEIGHTED traces the same rays to the same hits
+ * but gives every ray the product of the factors on its path from the root and adds weight x
+ * surface colour at every hit: no frames, no unwinding, and parked refracted rays that any idle
+ * lane can trace.  Its colours differ from the reference's in the last bits (re-association: a few
+ * 1e-16 relative, tested to 1e-9 absolute and to identical 8-bit values except <= 1 LSB on <= 0.01 %
+ * of the channels) and, in pixels whose subtrees were shared between lanes, from run to run.  Ray
+ * counts and every other statistic are the same.  It cannot render in place into a canvas shared
+ * between ranks (rtc_render_device_to_canvas with tile_ranks > 1). */
+#define RTC_INTEGRATOR_POSTORDER 0
+#define RTC_INTEGRATOR_WEIGHTED 1
+int rtc_scene_set_integrator(RtcScene* scene, int32_t integrator);
+
 /* The sweep table is grouped by kind of test; each group is swept by a loop specialised for it.
  * rtc_sweep_group_info describes group `group` (0 <= group < RTC_SWEEP_GROUPS): the Shape.geo value
  * it serves, whether it is the variant for inverses with exact zeros (a sphere whose inverse's 3x3

@@ -220,6 +220,7 @@ struct RtcScene {
     rtc::BvhNode* d_bvh = nullptr;
     int32_t bvh_root = 0;
     double bvh_origin_limit = 0;
+    int32_t integrator = RTC_INTEGRATOR_POSTORDER;  // rtc_scene_set_integrator
     void* h_staging = nullptr;  // pinned staging buffer of rtc_render's copy to the host, kept between calls
     size_t staging_bytes = 0;
     std::vector<hipEvent_t> slice_events;
@@ -827,6 +828,11 @@ int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, 
         std::snprintf(buf, sizeof buf, "scene was created on device %d but device %d is current", s->device, current_device);
         return fail(RTC_ERR_INVALID_ARGUMENT, buf);
     }
+    job.weighted = s->integrator == RTC_INTEGRATOR_WEIGHTED ? 1 : 0;
+    if (job.weighted && job.out_row_major && job.tile_ranks > 1)
+        return fail(RTC_ERR_INVALID_ARGUMENT,
+                    "the weighted integrator adds to its output with atomics and renders a partition into its own tile "
+                    "buffer only (rtc_render_device), not in place into a shared canvas");
     if (!control) control = s->d_counter;
     uint64_t* control_stats = (uint64_t*)((char*)control + rtc::kStatsOffsetBytes);
     job.counter = control;
@@ -1224,6 +1230,14 @@ int rtc_scene_destroy(RtcScene* scene) {
             if (slot.plan_scene == scene) slot.plan_valid = false;
     }
     free_scene(scene);
+    return RTC_OK;
+}
+
+int rtc_scene_set_integrator(RtcScene* scene, int32_t integrator) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (integrator != RTC_INTEGRATOR_POSTORDER && integrator != RTC_INTEGRATOR_WEIGHTED)
+        return fail(RTC_ERR_INVALID_ARGUMENT, "unknown integrator");
+    scene->integrator = integrator;
     return RTC_OK;
 }
 

@@ -156,6 +156,7 @@ struct DevJob {
     // costliest first, or nullptr for the natural order.  Only the schedule depends on it.
     const uint32_t* tile_order;
     int32_t depth;
+    int32_t weighted;  // 1: the attenuation-weighted integrator (render_weighted_kernel) instead of the post-order one
     double* out;
     uint32_t* counter;  // control block: the work-queue heads first, zeroed before the launch
     uint64_t* stats;    // 9 counters (radiance, shadow, sphere hits, plane hits, shaded, sphere skips, plane skips, cube hits, prefilter skips) or nullptr

@@ -1097,102 +1097,20 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
         // from the global queue with one atomic, and deals them to its lanes as they fall
         // idle.  A wave therefore works on one or two neighbouring blocks at a time, which
         // keeps the rays of its lanes alike (same shapes hit, same shading branches).
-        for (int pass = 0; pass < 2; ++pass) {
-            const unsigned long long idle = __ballot(mode == kIdle);
-            if (idle == 0) break;
-            if (loc_next >= loc_end) {
-                if (exhausted) break;
-                // Draw the next block of this wave's current queue.  Queue q hands out the blocks
-                // q, q + kQueues, q + 2 kQueues, ...; a queue that has run out sends the wave on to
-                // the next open one, and once all have run out the wave is done drawing.
-                const uint32_t n_blocks = (job.total + (uint32_t)kChunk - 1) / (uint32_t)kChunk;
-                uint32_t turn = 0;
-                if (lane == 0) turn = atomicAdd(g_counter + cur_queue * kQueueStrideWords, 1u);
-                turn = (uint32_t)__builtin_amdgcn_readfirstlane((int)turn);
-                const unsigned long long block = (unsigned long long)turn * kQueues + cur_queue;
-                if (block >= n_blocks) {
-                    // one look at all heads (they only grow, so a queue seen empty stays empty)
-                    uint32_t head = 0;
-                    if (lane < kQueues) head = __atomic_load_n(g_counter + lane * kQueueStrideWords, __ATOMIC_RELAXED);
-                    const bool has_blocks = lane < kQueues && (unsigned long long)head * kQueues + (unsigned)lane < n_blocks;
-                    const unsigned long long open_queues = __ballot(has_blocks);
-                    if (open_queues == 0) {
-                        exhausted = true;
-#ifdef RTC_PROBE
-                        if (probe_tx == 0) probe_tx = wall_clock64();
-#endif
-                    } else {
-                        // the first open queue after the current one, cyclically
-                        const unsigned long long after = open_queues & ~((2ull << cur_queue) - 1ull);
-                        cur_queue = (uint32_t)__ffsll((long long)(after ? after : open_queues)) - 1u;
-                    }
-                    break;
-                }
-                const uint32_t base = (uint32_t)block * (uint32_t)kChunk;
-                loc_next = base;
-                loc_end = base + (uint32_t)kChunk < job.total ? base + (uint32_t)kChunk : job.total;
-                if (!FROM_RAYS) {
-                    // where the block lies, once per draw and wave-uniform: queue position ->
-                    // (queue slot of the tile, 8x8 block of the tile) -> local tile -> global tile
-                    const uint32_t tile_px = RTC_TILE_W * RTC_TILE_H;
-                    const uint32_t slot = base / tile_px, blk = (base % tile_px) / (uint32_t)kChunk;
-                    const uint32_t lt = g_tile_order ? g_tile_order[slot] : slot;
-                    const uint32_t gt = lt * job.tile_ranks + job.tile_rank;
-                    blk_base = base;
-                    blk_px0 = (gt % job.tiles_x) * RTC_TILE_W + blk * 8;
-                    blk_py0 = (gt / job.tiles_x) * RTC_TILE_H;
-                    blk_valid = gt < job.tiles_total;
-                    // canvas pixel of the block's first pixel, or its slot in the rank's dense tile buffer
-                    blk_out0 = job.out_row_major ? blk_py0 * job.hsize + blk_px0 : lt * tile_px + blk * 8;
-                }
-            }
-            const uint32_t avail = loc_end - loc_next;
-            const uint32_t rank_in_wave = set_bits_below_lane(idle);
-            if (mode == kIdle && rank_in_wave < avail) {
-                const uint32_t k = loc_next + rank_in_wave;
-                bool got_work = false;
-                if (FROM_RAYS) {
-                    const double* r = g_rays + (size_t)k * 6;
-                    ro = {r[0], r[1], r[2]};
-                    rd = {r[3], r[4], r[5]};
-                    out_pixel = k;
-                    got_work = true;
-                } else {
-                    // pixel of the block: 8 positions per row
-                    const uint32_t r = k - blk_base;
-                    const uint32_t tx = r % 8, ty = r / 8;
-                    const uint32_t px = blk_px0 + tx, py = blk_py0 + ty;
-                    if (blk_valid && px < job.hsize && py < job.vsize) {
-                        // Camera.rayForPixel (camera.zig:48-72)
-                        const JobArg ja = job_argument();
-                        double cam_inv[12];
-#pragma unroll
-                        for (int q = 0; q < 12; ++q) cam_inv[q] = ja->cam_inv[q];
-                        const V3 cam_origin = {ja->cam_origin[0], ja->cam_origin[1], ja->cam_origin[2]};
-                        const double x_offset = ((double)px + 0.5) * ja->pixel_size;
-                        const double y_offset = ((double)py + 0.5) * ja->pixel_size;
-                        const double world_x = ja->half_width - x_offset;
-                        const double world_y = ja->half_height - y_offset;
-                        const V3 pixel = xform_point(cam_inv, V3{world_x, world_y, -1.0});
-                        ro = cam_origin;
-                        rd = normalize3(V3{pixel.x - cam_origin.x, pixel.y - cam_origin.y, pixel.z - cam_origin.z});
-                        const uint32_t row_stride = job.out_row_major ? job.hsize : (uint32_t)RTC_TILE_W;
-                        out_pixel = blk_out0 + ty * row_stride + tx;
-                        got_work = true;
-                    }
-                }
-                if (got_work) {
 #ifdef RTC_COSTMAP
-                    cost_nodes = 0;
+#define RTC_COSTMAP_RESET() cost_nodes = 0
+#else
+#define RTC_COSTMAP_RESET() (void)0
 #endif
-                    mode = kRun;
-                    aux = job.depth << kAuxRemShift;
-                    sp = 0;
-                }
-            }
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            loc_next += n_idle < avail ? n_idle : avail;
-        }
+#define RTC_START_TASK()                  \
+    do {                                  \
+        RTC_COSTMAP_RESET();              \
+        mode = kRun;                      \
+        aux = job.depth << kAuxRemShift;  \
+        sp = 0;                           \
+    } while (0)
+#include "rtc_refill.inc"
+#undef RTC_START_TASK
         const bool drained = exhausted && loc_next >= loc_end;  // wave-uniform: no pixel left to start
 
         bool have_ret = false;     // a finished subtree colour is in `ret`, to be unwound into the frames
@@ -1290,155 +1208,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 
             have_ret = true;
             if (hit.idx >= 0) {
-                if (STATS) ++n_shaded;
-                const bool exit_open = (hit.idx & kExitOpenBit) != 0;
-                hit.idx &= ~kExitOpenBit;
-                const DevShade& sh = shade_of(hit.idx);
-                const double* __restrict__ oinv = inverse_of(hit.idx);
-                const int geo = sh.geo;
-
-                // ---- calc.prepareComputations (calc.zig:247-306)
-                const V3 point = {ro.x + hit.t * rd.x, ro.y + hit.t * rd.y, ro.z + hit.t * rd.z};
-                const V3 eyev = {-rd.x, -rd.y, -rd.z};
-                // Shape.normalAt (shape.zig:84-97)
-                V3 normalv;
-                if (geo != RTC_GEO_PLANE) {
-                    // gather what the normal needs in one batch (the loads overlap each other)
-                    double M[12];
-#pragma unroll
-                    for (int q = 0; q < 11; ++q) M[q] = oinv[q];
-                    M[11] = oinv[11];
-                    const V3 lp = xform_point(M, point);
-                    V3 ln;
-                    if (geo == RTC_GEO_SPHERE) {
-                        ln = normalize3(lp);  // shape.zig:18-21
-                    } else {
-                        // extension: the face of the cube the point lies on (largest |coordinate|, x before y before z)
-                        const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
-                        const double maxc = max_cmp(max_cmp(ax, ay), az);
-                        const bool fx = maxc == ax, fy = !fx && maxc == ay;
-                        ln = {fx ? lp.x : 0.0, fy ? lp.y : 0.0, (fx || fy) ? 0.0 : lp.z};
-                    }
-                    normalv = normalize3(V3{(M[0] * ln.x + M[4] * ln.y) + M[8] * ln.z,
-                                            (M[1] * ln.x + M[5] * ln.y) + M[9] * ln.z,
-                                            (M[2] * ln.x + M[6] * ln.y) + M[10] * ln.z});
-                } else {
-                    // a plane's normal does not depend on the point: evaluated at upload
-                    normalv = {sh.plane_normal[0], sh.plane_normal[1], sh.plane_normal[2]};
-                }
-                // normalv.dot(eyev) decides the flip (calc.zig:256-259); eyev.dot(normalv) of the
-                // refraction terms and ray.direction.dot(normalv) of reflect() are the same three
-                // products and two sums up to signs, which rounding does not see
-                const double n_dot_e = dot3(normalv, eyev);
-                const bool inside = n_dot_e < 0;
-                if (inside) normalv = {-normalv.x, -normalv.y, -normalv.z};
-                const double cos_i = inside ? -n_dot_e : n_dot_e;
-                const V3 offs = {kSurfaceEps * normalv.x, kSurfaceEps * normalv.y, kSurfaceEps * normalv.z};
-                const V3 over_point = {point.x + offs.x, point.y + offs.y, point.z + offs.z};
-
-                // ---- calc.isShadowed (calc.zig:777-790) at over_point
-                if (STATS) ++n_shadow;
-                const WorldArg wa = world_argument();
-                const V3 light = {wa->light_pos[0], wa->light_pos[1], wa->light_pos[2]};
-                const V3 lv = {light.x - over_point.x, light.y - over_point.y, light.z - over_point.z};
-                const double distance = sqrt((lv.x * lv.x + lv.y * lv.y) + lv.z * lv.z);
-                const V3 lightv = {lv.x / distance, lv.y / distance, lv.z / distance};
-                Sweep sh_hit;
-                sh_hit.t = distance;
-                RTC_STAMP(pc_prep);
-                sweep_world<true, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_s, g_pairs_s, w, over_point, lightv, sh_hit, containers, ctr);
-                RTC_STAMP(pc_sweep2);
-                const bool in_shadow = sh_hit.idx >= 0;
-
-                // material and refractive indices in one batch of gathers
-                const double m_ambient = sh.ambient, m_diffuse = sh.diffuse, m_specular = sh.specular,
-                             m_shininess = sh.shininess, m_reflective = sh.reflective,
-                             m_transparency = sh.transparency, m_ri = sh.refractive_index;
-                const int m_pattern = sh.pattern, m_shininess_n = sh.shininess_n;
-                V3 color = {sh.color[0], sh.color[1], sh.color[2]};
-                // n1 / n2 from the open containers
-                const int rest = (hit.top1 == hit.idx) ? hit.top2 : hit.top1;
-                const double ri_top1 = hit.top1 < 0 ? 1.0 : shade_of(hit.top1).refractive_index;
-                const double ri_rest = rest < 0 ? 1.0 : shade_of(rest).refractive_index;
-                const double n1 = ri_top1;
-                const double n2 = exit_open ? ri_rest : m_ri;
-                // the rest of calc.prepareComputations (deferred past the shadow sweep: fewer live registers)
-                const double two_dp = 2.0 * -cos_i;  // Vec4.reflect, vector.zig:114-117: 2 * direction.dot(normalv)
-                const V3 reflectv = {rd.x - two_dp * normalv.x, rd.y - two_dp * normalv.y, rd.z - two_dp * normalv.z};
-                const V3 under_point = {point.x - offs.x, point.y - offs.y, point.z - offs.z};
-
-                RTC_STAMP(pc_gather);
-                // ---- calc.lighting (calc.zig:26-73) at over_point; lightv above is the same
-                // light.position.sub(position).normalize() the reference recomputes
-                if (m_pattern >= 0) color = pattern_color(sh, oinv, over_point);
-                RTC_STAMP(pc_pattern);
-                const WorldArg wl = world_argument();
-                const V3 lint = {wl->light_int[0], wl->light_int[1], wl->light_int[2]};
-                const V3 eff = {color.x * lint.x, color.y * lint.y, color.z * lint.z};
-                V3 surface = {m_ambient * eff.x, m_ambient * eff.y, m_ambient * eff.z};
-                const double light_dot_normal = dot3(lightv, normalv);
-                if (light_dot_normal > 0.0 && !in_shadow) {
-                    const double kd = m_diffuse * light_dot_normal;
-                    surface = {surface.x + kd * eff.x, surface.y + kd * eff.y, surface.z + kd * eff.z};
-                    const V3 nl = {-lightv.x, -lightv.y, -lightv.z};
-                    const double two_ln = 2.0 * dot3(nl, normalv);
-                    const V3 lr = {nl.x - two_ln * normalv.x, nl.y - two_ln * normalv.y, nl.z - two_ln * normalv.z};
-                    const double reflect_dot_eye = dot3(lr, eyev);
-                    // specular == 0 scales a finite power (base at most 2, exponent below 500) to
-                    // zero, and adding that zero changes no value: the power is not evaluated
-                    const bool no_specular = m_specular == 0.0 && m_shininess_n > 0 && reflect_dot_eye <= 2.0;
-                    if (reflect_dot_eye > 0.0 && !no_specular) {
-                        const double pw = m_shininess_n > 0
-                                              ? pow_small_integer(reflect_dot_eye, m_shininess_n)
-                                              : zig_pow(reflect_dot_eye, m_shininess);
-                        const double ks = m_specular * pw;
-                        surface = {surface.x + ks * lint.x, surface.y + ks * lint.y, surface.z + ks * lint.z};
-                    }
-                }
-
-                RTC_STAMP(pc_light);
-                // ---- children: calc.reflectedColor (945-959), calc.refractedColor (828-853)
-                const bool has_reflect = remaining > 0 && !(fabs(m_reflective) <= kF64Eps);
-                bool has_refract = false;
-                V3 refr_dir = {0, 0, 0};
-                // calc.refractedColor (calc.zig:836-846) and, leaving a denser medium, calc.schlick
-                // (calc.zig:1010-1018) form the same ratio, sin2_t and cos_t from the same values:
-                // evaluated once for both
-                const bool refract_wanted = remaining > 0 && !(fabs(m_transparency) <= kF64Eps);
-                const bool schlick_wanted = m_reflective > 0.0 && m_transparency > 0.0;
-                double n_ratio = 0.0, sin2_t = 0.0, cos_t = 0.0;
-                if (refract_wanted || (schlick_wanted && n1 > n2)) {
-                    n_ratio = n1 / n2;
-                    sin2_t = n_ratio * n_ratio * (1 - cos_i * cos_i);
-                    if (!(sin2_t > 1.0)) cos_t = sqrt(1.0 - sin2_t);
-                }
-                if (refract_wanted && !(sin2_t > 1.0)) {
-                    const double kn = n_ratio * cos_i - cos_t;
-                    refr_dir = {kn * normalv.x - n_ratio * eyev.x, kn * normalv.y - n_ratio * eyev.y,
-                                kn * normalv.z - n_ratio * eyev.z};
-                    has_refract = true;
-                }
-                int flags = has_refract ? kHasRefract : 0;
-                double R = 0.0;
-                if (schlick_wanted) {
-                    // calc.schlick (calc.zig:1004-1026)
-                    flags |= kSchlick;
-                    double cosv = cos_i;
-                    bool tir = false;
-                    if (n1 > n2) {
-                        if (sin2_t > 1.0)
-                            tir = true;
-                        else
-                            cosv = cos_t;
-                    }
-                    if (tir) {
-                        R = 1.0;
-                    } else {
-                        const double r0 = pow_small_integer((n1 - n2) / (n1 + n2), 2);
-                        R = r0 + (1 - r0) * pow_small_integer(1 - cosv, 5);
-                    }
-                }
-                RTC_STAMP(pc_children);
+#include "rtc_node.inc"
                 if (has_reflect || has_refract) {
                     // a frame holds only what its unwinding will read: most frames (a reflective,
                     // opaque surface) are the colour so far and the meta word
@@ -1563,6 +1333,262 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
     }
 }
 
+#undef RTC_STAMP
+#define RTC_STAMP(acc) \
+    do {               \
+    } while (0)
+
+// The attenuation-weighted integrator (rtc_scene_set_integrator: RTC_INTEGRATOR_WEIGHTED).
+//
+// The reference's recursion (calc.zig:460-469) multiplies a child's colour by the factors of every
+// ancestor on the way back up: reflective or transparency (calc.zig:958,852), and the Schlick share
+// (calc.zig:466).  The same sum, taken the other way round: a ray carries the product of the
+// factors on its path from the root, every hit adds weight x surface colour to the pixel, and a
+// child starts with weight x its factor.  Same rays, same hits, same surface colours as the
+// post-order kernel; what differs is the association of the products and of the sum, i.e. the
+// last bits of a colour (a few 1e-16 relative; the parity tests allow 1e-9).  What it saves: a hit
+// with one child pushes nothing (the post-order kernel parks a frame for it), there is no pass
+// that unwinds finished subtrees, and a parked refracted ray is an independent piece of work: any
+// idle lane can trace it and add its share to the pixel on its own.
+//   per lane: the ray, its weight and `remaining`, the colour gathered so far for the pixel, and a
+//   stack of parked refracted rays (ray, weight, remaining), pushed only by hits with two children.
+//   Once the pixel queue is empty, idle lanes take over parked rays of busy lanes of the wave (the
+//   shallowest first).  The pixel then has several contributors; each adds its share with atomic
+//   additions, the owner having stored zeros when it first gave a ray away.  Sums arriving in a
+//   different order are why this integrator's last bits can differ from run to run.
+// A non-finite Schlick reflectance does not poison a childless hit's colour as calc.zig:466 would
+// (weights only reach children).
+template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
+__global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_weighted_kernel(
+    const double* __restrict__ g_tab, const DevShade* __restrict__ g_shade, const int* __restrict__ g_order,
+    const double* __restrict__ g_rays, const uint32_t* __restrict__ g_tile_order, double* __restrict__ g_out,
+    uint32_t* __restrict__ g_counter, unsigned long long* __restrict__ g_stats, const double* __restrict__ g_bounds_r,
+    const double* __restrict__ g_bounds_s, const double* __restrict__ g_inv, const float* __restrict__ g_pairs_r,
+    const float* __restrict__ g_pairs_s, const DevWorld wc, const DevJob job) {
+    constexpr bool LDS = TABLES == 1;
+    constexpr bool ACCEL = TABLES == 2;
+    constexpr bool STREAM = TABLES == 0;
+    __shared__ ContainerSlots containers;
+    __shared__ HotTables<LDS> hot;
+    const int tid = (int)threadIdx.x;
+    if constexpr (LDS) {
+        const int n = wc.n;
+        for (int k = (int)threadIdx.x; k < n * 12; k += kBlock) hot.mat[k / 12][k % 12] = g_inv[k];
+        const double* __restrict__ src = reinterpret_cast<const double*>(g_shade);
+        double* dst = reinterpret_cast<double*>(hot.shade);
+        for (int k = (int)threadIdx.x; k < n * (int)(sizeof(DevShade) / 8); k += kBlock) dst[k] = src[k];
+        __syncthreads();
+    }
+    auto shade_of = [&](int i) -> const DevShade& {
+        if constexpr (LDS)
+            return hot.shade[i];
+        else
+            return g_shade[i];
+    };
+    auto inverse_of = [&](int i) -> const double* {
+        if constexpr (LDS)
+            return hot.mat[i];
+        else
+            return g_inv + (size_t)i * 12;
+    };
+    const double* __restrict__ sweep_tab = g_tab;
+    const int lane = (int)(threadIdx.x & 63);
+    DevWorld w = wc;
+    w.tab = g_tab;
+    w.shade = g_shade;
+
+    // parked refracted rays of the lane (private memory): ray, weight, remaining
+    double p_ray[MAXD][6];
+    double p_w[MAXD];
+    int p_rem[MAXD];
+
+    uint32_t n_radiance = 0, n_shadow = 0, n_shaded = 0;
+    SweepCounters ctr = {};
+
+    int mode = kIdle;
+    uint32_t out_pixel = 0;
+    int sp = 0;             // parked rays on the lane's stack
+    uint32_t stolen = 0;    // bit f: entry f of the stack was taken over by another lane
+    bool shared = false;    // the pixel has (or may get) other contributors: add, do not store
+    int rem = 0;            // `remaining` (calc.zig:641) of the ray being traced
+    double wgt = 0.0;       // product of the factors on the path from the pixel's root to this ray
+    V3 acc = {0, 0, 0};     // the task's share of the pixel so far
+    V3 ro = {0, 0, 0}, rd = {0, 0, 0};
+    bool exhausted = false;
+    uint32_t loc_next = 0, loc_end = 0;
+    uint32_t cur_queue = ((blockIdx.x * (kBlock / 64)) + (threadIdx.x >> 6)) % kQueues;
+    uint32_t blk_base = 0, blk_px0 = 0, blk_py0 = 0;
+    bool blk_valid = false;
+    uint32_t blk_out0 = 0;
+#ifdef RTC_PROBE
+    unsigned long long probe_tx = 0;
+#endif
+
+    for (;;) {
+#define RTC_START_TASK()      \
+    do {                      \
+        mode = kRun;          \
+        rem = job.depth;      \
+        wgt = 1.0;            \
+        acc = V3{0, 0, 0};    \
+        sp = 0;               \
+        stolen = 0;           \
+        shared = false;       \
+    } while (0)
+#include "rtc_refill.inc"
+#undef RTC_START_TASK
+        const bool drained = exhausted && loc_next >= loc_end;
+
+        // ---- queue empty: idle lanes take over parked rays -------------------------------------
+        if (drained) {
+            int offer_f = -1;
+            if (mode == kRun) {
+#pragma unroll
+                for (int f = MAXD - 1; f >= 0; --f)
+                    if (f < sp && !((stolen >> f) & 1u)) offer_f = f;  // ends at the shallowest
+            }
+            const unsigned long long offers = __ballot(offer_f >= 0);
+            const unsigned long long idles = __ballot(mode == kIdle);
+            if (offers != 0 && idles != 0) {
+                const int n_off = __popcll(offers), n_idle = __popcll(idles);
+                const int n_pairs = n_off < n_idle ? n_off : n_idle;
+                const int my_off = (int)set_bits_below_lane(offers), my_idle = (int)set_bits_below_lane(idles);
+                const bool give = offer_f >= 0 && my_off < n_pairs;
+                const bool take = mode == kIdle && my_idle < n_pairs;
+                int partner = lane;
+                if (give) partner = nth_set_bit(idles, my_off);
+                if (take) partner = nth_set_bit(offers, my_idle);
+                double p[7] = {0, 0, 0, 0, 0, 0, 0};
+                int p_r = 0;
+                if (give) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) p[q] = p_ray[offer_f][q];
+                    p[6] = p_w[offer_f];
+                    p_r = p_rem[offer_f];
+                    stolen |= 1u << offer_f;
+                    if (!shared) {
+                        // the pixel gets a second contributor: from here on everybody adds, to zeros
+                        double* __restrict__ px_out = g_out + (size_t)out_pixel * 3;
+                        px_out[0] = 0.0;
+                        px_out[1] = 0.0;
+                        px_out[2] = 0.0;
+                        shared = true;
+                    }
+                }
+                // the zeros are in place before any lane of this wave can add to them
+                __threadfence();
+                double t7[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) t7[q] = __shfl(p[q], partner);
+                const int t_rem = __shfl(p_r, partner);
+                const uint32_t t_pixel = (uint32_t)__shfl((int)out_pixel, partner);
+                if (take) {
+                    ro = {t7[0], t7[1], t7[2]};
+                    rd = {t7[3], t7[4], t7[5]};
+                    wgt = t7[6];
+                    rem = t_rem;
+                    out_pixel = t_pixel;
+                    acc = V3{0, 0, 0};
+                    sp = 0;
+                    stolen = 0;
+                    shared = true;
+                    mode = kRun;
+                }
+            }
+        }
+        if (__ballot(mode != kIdle) == 0) {
+            if (drained) break;
+            continue;
+        }
+
+        if (mode == kRun) {
+            // ---- one tree node: calc.worldColorAt (calc.zig:641-652) ---------------------
+            if (STATS) ++n_radiance;
+            const int remaining = rem;
+            Sweep hit;
+            sweep_world<false, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_r, g_pairs_r, w, ro, rd, hit, containers, ctr);
+            bool chain_ends = true;  // a miss adds Color.Black (calc.zig:650)
+            if (hit.idx >= 0) {
+#include "rtc_node.inc"
+                acc = {acc.x + wgt * surface.x, acc.y + wgt * surface.y, acc.z + wgt * surface.z};
+                // color.scale(reflective) [.scale(reflectance)] and color.scale(transparency)
+                // [.scale(1 - reflectance)] (calc.zig:958,852,466) as factors of the children's weights
+                double w_reflect = wgt * m_reflective, w_refract = wgt * m_transparency;
+                if (flags & kSchlick) {
+                    w_reflect = w_reflect * R;
+                    w_refract = w_refract * (1.0 - R);
+                }
+                if (has_reflect || has_refract) {
+                    if (has_reflect && has_refract) {
+                        p_ray[sp][0] = under_point.x;
+                        p_ray[sp][1] = under_point.y;
+                        p_ray[sp][2] = under_point.z;
+                        p_ray[sp][3] = refr_dir.x;
+                        p_ray[sp][4] = refr_dir.y;
+                        p_ray[sp][5] = refr_dir.z;
+                        p_w[sp] = w_refract;
+                        p_rem[sp] = rem - 1;
+                        ++sp;
+                    }
+                    if (has_reflect) {
+                        ro = over_point;
+                        rd = reflectv;
+                        wgt = w_reflect;
+                    } else {
+                        ro = under_point;
+                        rd = refr_dir;
+                        wgt = w_refract;
+                    }
+                    rem = rem - 1;
+                    chain_ends = false;
+                }
+            }
+            if (chain_ends) {
+                // the next parked ray nobody has taken, or the task is complete
+                bool resumed = false;
+#pragma unroll
+                for (int L = MAXD - 1; L >= 0; --L) {
+                    if (!resumed && sp == L + 1) {
+                        sp = L;
+                        if (!((stolen >> L) & 1u)) {
+                            ro = {p_ray[L][0], p_ray[L][1], p_ray[L][2]};
+                            rd = {p_ray[L][3], p_ray[L][4], p_ray[L][5]};
+                            wgt = p_w[L];
+                            rem = p_rem[L];
+                            resumed = true;
+                        }
+                        stolen &= ~(1u << L);
+                    }
+                }
+                if (!resumed) {
+                    // canvas.set (canvas.zig:24-28), or this task's share of it
+                    double* __restrict__ px_out = g_out + (size_t)out_pixel * 3;
+                    if (shared) {
+                        __hip_atomic_fetch_add(px_out + 0, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(px_out + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(px_out + 2, acc.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        px_out[0] = acc.x;
+                        px_out[1] = acc.y;
+                        px_out[2] = acc.z;
+                    }
+                    mode = kIdle;
+                }
+            }
+        }
+    }
+
+    if (STATS) {
+        uint32_t v[9] = {n_radiance, n_shadow, ctr.sphere_hits, ctr.plane_hits, n_shaded, ctr.sphere_skips, ctr.plane_skips,
+                         ctr.cube_hits, ctr.sphere_prefilter_skips};
+        for (int c = 0; c < 9; ++c) {
+            unsigned long long sum = v[c];
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+            if (lane == 0) atomicAdd(&g_stats[c], sum);
+        }
+    }
+}
+
 // Scatter gathered per-rank tile buffers into the row-major canvas.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void deinterleave_kernel(const T* __restrict__ gathered,
@@ -1636,7 +1662,7 @@ __global__ __launch_bounds__(kBlock) void arith_probe_kernel(const double* __res
 
 template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
 hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t stream) {
-    auto kernel = render_kernel<MAXD, STATS, FROM_RAYS, TABLES>;
+    auto kernel = job.weighted ? render_weighted_kernel<MAXD, STATS, FROM_RAYS, TABLES> : render_kernel<MAXD, STATS, FROM_RAYS, TABLES>;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

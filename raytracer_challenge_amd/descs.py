@@ -27,6 +27,8 @@ RTC_PATTERN_CHECKERS = 4
 
 RTC_ACCEL_NONE = 0
 RTC_ACCEL_BVH = 1
+RTC_INTEGRATOR_POSTORDER = 0
+RTC_INTEGRATOR_WEIGHTED = 1
 RTC_NOALLOC_MAX_TILES = 262144
 RTC_MULTI_MAX_RANKS = 64
 RTC_IPC_HANDLE_BYTES = 64

@@ -10,6 +10,8 @@ sys.path.insert(0, %r)
 import torch
 from raytracer_challenge_amd import native, scenes, descs as D
 wl = sys.argv[1]
+weighted = wl.endswith("w")  # e.g. c3w: the same workload with the attenuation-weighted integrator
+if weighted: wl = wl[:-1]
 if wl == "c3": world, cam = scenes.draw_world_scene(3840, 2160)
 elif wl == "c2": world, cam = scenes.draw_world_scene(1920, 1080)
 elif wl == "c5": world, cam = scenes.draw_world_scene(7680, 4320)
@@ -19,6 +21,7 @@ elif wl == "c4s": world, cam = scenes.synthetic_scene(960, 540)
 elif wl == "c4": world, cam = scenes.synthetic_scene(3840, 2160)
 cd = cam.desc()
 sc = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
+if weighted: sc.set_integrator(D.RTC_INTEGRATOR_WEIGHTED)
 out = torch.empty(cd.hsize * cd.vsize * 3, dtype=torch.float64, device="cuda")
 DEPTH = int(os.environ.get('RTC_AB_DEPTH', '5'))
 for _ in range(2): sc.render_device(cd, DEPTH, out.data_ptr())
