@@ -46,7 +46,12 @@ def main():
     for wl in a.workloads.split(","):
         for r in range(a.rounds):
             for lib in a.libs:
-                env = dict(os.environ, RTC_HIP_LIB=os.path.abspath(lib))
+                # a "library" may carry environment settings: lib.so:NAME=value[:NAME=value]
+                parts = lib.split(":")
+                env = dict(os.environ, RTC_HIP_LIB=os.path.abspath(parts[0]))
+                for kv in parts[1:]:
+                    k, v = kv.split("=", 1)
+                    env[k] = v  # RTC_AB_ENV
                 p = subprocess.run([sys.executable, "-c", CHILD, wl, str(a.iters)], env=env, capture_output=True, text=True, timeout=600)
                 if p.returncode != 0:
                     print("FAILED", lib, wl, p.stderr[-2000:]); continue
