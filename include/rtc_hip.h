@@ -326,6 +326,10 @@ int rtc_multi_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                      const int32_t* devices, uint32_t n_ranks, RtcMulti** out_multi);
 int rtc_multi_destroy(RtcMulti* multi);
 int rtc_multi_rank_device(const RtcMulti* multi, uint32_t rank, int32_t* out_device);
+/* rtc_scene_set_integrator for every rank's replica.  With RTC_INTEGRATOR_WEIGHTED and more than one rank the
+ * modes that work on tile buffers apply (scatter, RCCL gather, host-direct); RTC_MULTI_PEER_STORES renders in
+ * place into rank 0's canvas, which that integrator cannot do, and fails with RTC_ERR_INVALID_ARGUMENT. */
+int rtc_multi_set_integrator(RtcMulti* multi, int32_t integrator);
 
 /* How the ranks' pixels reach rank 0's canvas. */
 #define RTC_MULTI_PEER_STORES 0  /* render kernels store into rank 0's canvas through peer access */

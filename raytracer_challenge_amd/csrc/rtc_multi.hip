@@ -484,6 +484,19 @@ int rtc_multi_destroy(RtcMulti* multi) {
     return RTC_OK;
 }
 
+int rtc_multi_set_integrator(RtcMulti* multi, int32_t integrator) {
+    if (!multi) return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "multi is NULL");
+    int previous = 0;
+    MULTI_HIP(hipGetDevice(&previous));
+    int rc = RTC_OK;
+    for (uint32_t r = 0; r < multi->ranks && rc == RTC_OK; ++r) {
+        const hipError_t e = hipSetDevice(multi->device[r]);
+        rc = e != hipSuccess ? rtc::set_hip_error("hipSetDevice", e) : rtc_scene_set_integrator(multi->scene[r], integrator);
+    }
+    (void)hipSetDevice(previous);
+    return rc;
+}
+
 int rtc_multi_rank_device(const RtcMulti* multi, uint32_t rank, int32_t* out_device) {
     if (!multi || !out_device || rank >= multi->ranks) return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "bad rank or NULL pointer");
     *out_device = multi->device[rank];

@@ -365,12 +365,15 @@ class Camera:
         d.transform[:] = self.transform.flat()
         return d
 
-    def render(self, world, depth=5, stats=None):
+    def render(self, world, depth=5, stats=None, integrator=0):
         """Camera.render (camera.zig:74-89) through the HIP library.  The reference's
         hard-coded depth is 5 (camera.zig:83).  Raises RtcError on any non-zero status,
-        as the Zig glue maps it to an error from `render`'s `!Canvas`."""
+        as the Zig glue maps it to an error from `render`'s `!Canvas`.  `integrator`:
+        RTC_INTEGRATOR_POSTORDER (0, the reference's order of summation) or RTC_INTEGRATOR_WEIGHTED (1)."""
         from . import native
 
         with native.Scene(world.shape_descs(), len(world.objects), world.light_desc()) as scene:
+            if integrator:
+                scene.set_integrator(integrator)
             pixels = scene.render(self.desc(), depth, stats)
         return Canvas(self.hsize, self.vsize, pixels)

@@ -258,11 +258,14 @@ struct Camera {
     }
 
     // Camera.render (camera.zig:74-89) through the HIP library; the reference's depth is 5.
-    Canvas render(const World& world, int depth = 5, RtcStats* stats = nullptr) const {
+    // `integrator`: RTC_INTEGRATOR_POSTORDER (the reference's order of summation) or RTC_INTEGRATOR_WEIGHTED.
+    Canvas render(const World& world, int depth = 5, RtcStats* stats = nullptr,
+                  int integrator = RTC_INTEGRATOR_POSTORDER) const {
         // an empty canvas has no first pixel to point at: the library refuses it by name
         if (hsize == 0 || vsize == 0) throw RenderError(RTC_ERR_INVALID_ARGUMENT, "camera hsize/vsize must be non-zero");
         Canvas canvas(hsize, vsize);
         through_library(world, [&](RtcScene* scene, const RtcCameraDesc& cam) {
+            if (int rc = rtc_scene_set_integrator(scene, integrator)) return rc;
             return rtc_render(scene, &cam, depth, &canvas.pixels[0].red, stats);
         });
         return canvas;
@@ -270,10 +273,12 @@ struct Camera {
 
     // Camera.render and the byteColorValue half of canvasToPPM (ppm.zig:6-9) in one call: the
     // colours are quantised on the device and bytesToPPM only formats.
-    ByteCanvas renderBytes(const World& world, int depth = 5, RtcStats* stats = nullptr) const {
+    ByteCanvas renderBytes(const World& world, int depth = 5, RtcStats* stats = nullptr,
+                           int integrator = RTC_INTEGRATOR_POSTORDER) const {
         if (hsize == 0 || vsize == 0) throw RenderError(RTC_ERR_INVALID_ARGUMENT, "camera hsize/vsize must be non-zero");
         ByteCanvas canvas(hsize, vsize);
         through_library(world, [&](RtcScene* scene, const RtcCameraDesc& cam) {
+            if (int rc = rtc_scene_set_integrator(scene, integrator)) return rc;
             return rtc_render_u8(scene, &cam, depth, canvas.rgb.data(), stats);
         });
         return canvas;

@@ -60,6 +60,7 @@ def lib():
                                    C.POINTER(vp)]
     L.rtc_multi_destroy.argtypes = [vp]
     L.rtc_multi_rank_device.argtypes = [vp, u32, C.POINTER(i32)]
+    L.rtc_multi_set_integrator.argtypes = [vp, i32]
     L.rtc_render_multi.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, i32, dp, C.POINTER(D.RtcStats),
                                    C.POINTER(D.RtcMultiTiming)]
     L.rtc_render_multi_u8.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, i32, C.POINTER(C.c_uint8),
@@ -102,6 +103,7 @@ EXPORTS = (
     "rtc_multi_create",
     "rtc_multi_destroy",
     "rtc_multi_rank_device",
+    "rtc_multi_set_integrator",
     "rtc_render_multi",
     "rtc_render_multi_u8",
     "rtc_ipc_canvas_create",
@@ -326,6 +328,9 @@ class Multi:
             self.close()
         except Exception:
             pass
+
+    def set_integrator(self, integrator):
+        check(lib().rtc_multi_set_integrator(self._h, int(integrator)))
 
     def rank_device(self, rank):
         d = C.c_int32(-1)

@@ -137,3 +137,30 @@ def test_headline_frame_against_the_exact_integrator():
     rows = slice(7, 2160, 270)
     cpu = O.render(w, c, 5, O.STREAMING, rows=(7, 2160, 270))
     assert_close(weighted[rows], cpu[rows], "4K frame, sampled rows against the oracle")
+
+
+def test_weighted_integrator_over_several_ranks_of_one_process():
+    """rtc_multi_set_integrator: the modes that work on tile buffers give the canvas within the bar; the in-place
+    mode is refused."""
+    w, c = scenes.draw_world_scene(333, 97)
+    cd = c.desc()
+    want = O.render(w, c, 5, O.STREAMING)
+    with native.Multi(w.shape_descs(), len(w.objects), w.light_desc(), 3) as m:
+        m.set_integrator(D.RTC_INTEGRATOR_WEIGHTED)
+        for mode in (D.RTC_MULTI_PEER_SCATTER, D.RTC_MULTI_RCCL_GATHER, D.RTC_MULTI_HOST_DIRECT):
+            assert_close(m.render(cd, 5, mode), want, f"3 ranks, mode {mode}")
+            assert np.array_equal(m.render_u8(cd, 5, mode), byte_color_values(want)), f"3 ranks, mode {mode}, 8-bit"
+        with pytest.raises(native.RtcError) as e:
+            m.render(cd, 5, D.RTC_MULTI_PEER_STORES)
+        assert e.value.code == D.RTC_ERR_INVALID_ARGUMENT
+        m.set_integrator(D.RTC_INTEGRATOR_POSTORDER)
+        assert np.array_equal(m.render(cd, 5, D.RTC_MULTI_PEER_STORES), want)
+    with native.Multi(w.shape_descs(), len(w.objects), w.light_desc(), 1) as m:
+        m.set_integrator(D.RTC_INTEGRATOR_WEIGHTED)
+        assert_close(m.render(cd, 5, D.RTC_MULTI_PEER_STORES), want, "one rank")
+
+
+def test_host_mirror_takes_the_integrator():
+    w, c = scenes.draw_world_scene(96, 48)
+    exact = c.render(w, 5).pixels
+    assert_close(c.render(w, 5, integrator=D.RTC_INTEGRATOR_WEIGHTED).pixels, exact, "Camera.render(integrator=weighted)")
