@@ -188,6 +188,8 @@ struct RtcScene {
     double* d_inv = nullptr;            // rows 0..2 of inverse(shape.transform), 12 doubles per shape, table order
     float* d_sphere_pairs = nullptr;    // single-precision pre-test tables: radiance, then shadow (see DevWorld)
     size_t sphere_pairs_floats = 0;     // floats per table
+    uint32_t block_pairs_offset_radiance = 0, block_pairs_offset_shadow = 0;  // see DevWorld
+    double block_shrink = 0.0, block_margin_scale = 1.0;
     double* d_sphere_bounds = nullptr;  // radiance table, then shadow table (see DevWorld)
     size_t sphere_bounds_doubles = 0;   // doubles per table
     int32_t* d_order = nullptr;
@@ -261,6 +263,10 @@ rtc::DevWorld dev_world(const RtcScene* s) {
     w.inv = s->d_inv;
     w.sphere_pairs_radiance = s->d_sphere_pairs;
     w.sphere_pairs_shadow = s->d_sphere_pairs ? s->d_sphere_pairs + s->sphere_pairs_floats : nullptr;
+    w.block_pairs_offset_radiance = s->block_pairs_offset_radiance;
+    w.block_pairs_offset_shadow = s->block_pairs_offset_shadow;
+    w.block_shrink = s->block_shrink;
+    w.block_margin_scale = s->block_margin_scale;
     w.sphere_bounds_radiance = s->d_sphere_bounds;
     w.sphere_bounds_shadow = s->d_sphere_bounds ? s->d_sphere_bounds + s->sphere_bounds_doubles : nullptr;
     std::memcpy(w.group, s->group, sizeof w.group);
@@ -691,15 +697,64 @@ void plane_light_side(const double* inv12, const double* light_pos, double out[3
 //     |lc|^2 (1 - 2^-25) - bound[3] (1 + 2^-40) - 2^-25 dist^2 > (lc . d)^2 ,
 // whose left side is out[3] minus a per-ray term: three multiply-adds per sphere instead of the
 // origin's nine.  out[0..2] = lc.
-void sphere_from_light(const double* bound, const double* light_pos, double out[4]) {
+// (`eps` is the shrink of the test the bound belongs to: 2^-27 for a sphere's own, more for a block's; the
+// per-ray term is then 4 eps dist^2.)
+void sphere_from_light(const double* bound, const double* light_pos, double out[4], double eps = 0x1p-27) {
     double l2 = 0;
     for (int a = 0; a < 3; ++a) {
         out[a] = bound[a] - light_pos[a];
         l2 += out[a] * out[a];
     }
-    out[3] = l2 * (1.0 - 0x1p-25) - bound[3] * (1.0 + 0x1p-40);
+    out[3] = l2 * (1.0 - 4.0 * eps) - bound[3] * (1.0 + 0x1p-40);
     if (!std::isfinite(out[0]) || !std::isfinite(out[1]) || !std::isfinite(out[2]) || !(out[3] == out[3]))
         out[3] = -std::numeric_limits<double>::infinity();
+}
+
+// A sphere around the bounding spheres of a block of spheres, for the streamed sweep's block test: a ray that
+// passes it by the test's margin passes every member by the member's own margin, i.e. the block test may stand
+// in for the members' tests.  A member's test (sphere_bound) dismisses when
+//     D_i^2 > b_i + eps |c_i - o|^2 ,   eps = 2^-27 ,
+// D_i the distance of the ray's line from the member's centre c_i, b_i its enlarged squared radius.  The block's
+// test has the same form with centre C, squared radius R^2 and a shrink eps_B of its own.  With delta_i = |c_i - C|:
+// D_i >= D - delta_i and |c_i - o|^2 <= 2 |C - o|^2 + 2 delta_i^2, so it is enough that
+//     (D - delta_i)^2 > b_i + 2 eps delta_i^2 + 2 eps |C - o|^2 .
+// For D^2 > R^2 + z, z >= 0 and R >= delta:  (D - delta)^2 >= (R - delta)^2 + z (R - delta) / R
+// (expand both sides: the difference is delta (z / R - 2 (sqrt(R^2 + z) - R)) >= 0).  So with
+//     rho_i = sqrt(b_i + 2 eps delta_i^2) ,   R >= delta_i + rho_i for every member ,   eps_B >= 2 eps R / rho_i ,
+// the block's test D^2 > R^2 + eps_B |C - o|^2 gives (D - delta_i)^2 > rho_i^2 + 2 eps |C - o|^2, which is the
+// line above.  Roundings of this function are covered by the factors 1 + 2^-40; the centre is the mean of
+// the members' centres (any point would do).  A member without a bound leaves the block without one.
+struct BlockBound {
+    bool bounded = false;
+    double c[3] = {0, 0, 0};
+    double r2 = 0;   // R^2
+    double eps = 0;  // eps_B
+};
+BlockBound sphere_block_bound(const RtcScene::SphereBound* const* members, size_t n) {
+    BlockBound out;
+    if (n == 0) return out;
+    double c[3] = {0, 0, 0};
+    for (size_t k = 0; k < n; ++k) {
+        if (!members[k] || !std::isfinite(members[k]->b[3])) return out;
+        for (int a = 0; a < 3; ++a) c[a] += members[k]->b[a] / (double)n;
+    }
+    const double eps = 0x1p-27, up = 1.0 + 0x1p-40;
+    double R = 0, rho_min = std::numeric_limits<double>::infinity();
+    for (size_t k = 0; k < n; ++k) {
+        double d2 = 0;
+        for (int a = 0; a < 3; ++a) d2 += (members[k]->b[a] - c[a]) * (members[k]->b[a] - c[a]);
+        // (b[3] is the member's bound divided by 1 - 2^-27: not smaller than b_i)
+        const double rho = std::sqrt((members[k]->b[3] + 2.0 * eps * d2 * up) * up) * up;
+        R = std::fmax(R, (std::sqrt(d2 * up) * up + rho) * up);
+        rho_min = std::fmin(rho_min, rho);
+    }
+    if (!(rho_min > 0) || !std::isfinite(R)) return out;
+    out.bounded = true;
+    for (int a = 0; a < 3; ++a) out.c[a] = c[a];
+    out.r2 = R * R * up;
+    out.eps = 2.0 * eps * (R / rho_min) * up * up;
+    if (!std::isfinite(out.r2) || !std::isfinite(out.eps)) out.bounded = false;
+    return out;
 }
 
 // Single-precision operands of the packed pre-test that runs ahead of the bounding tests in the streamed sweep
@@ -1068,7 +1123,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     }
 
     std::vector<RtcScene::SphereBound> bounds;
-    // table order: the groups one after the other, each in list order
+    // table order: the groups one after the other
     std::vector<double> tab((n_shapes + 2) * kRec, 0.0);
     std::vector<double> inv_tab((n_shapes ? n_shapes : 1) * 12, 0.0);  // rows 0..2 of every inverse, table order (gathers)
     std::vector<int32_t> order(n_shapes ? n_shapes : 1, 0);
@@ -1076,10 +1131,56 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     int32_t group[rtc::kSweepGroups + 1] = {};
     {
         size_t pos = 0;
+        // Members of every group in list order; in a world too large for the on-chip tables the spheres of a
+        // group follow the Morton order of their centres instead, so that spheres that follow each other in the
+        // table lie close together and the streamed sweep can dismiss them a block at a time (sphere_block_bound).
+        // Nothing depends on the order inside a group: equal t are resolved by the list index kept with each record.
+        std::vector<std::vector<uint64_t>> members(rtc::kSweepGroups);
+        for (uint64_t i = 0; i < n_shapes; ++i)
+            if (group_of[i] >= 0) members[group_of[i]].push_back(i);
+        if (n_shapes > (uint64_t)rtc::kLdsShapeLimit) {
+            double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            bool any = false;
+            auto centre_ok = [&](uint64_t i) {
+                const double* t = shapes[i].transform;
+                return std::isfinite(t[3]) && std::isfinite(t[7]) && std::isfinite(t[11]);
+            };
+            for (uint64_t i = 0; i < n_shapes; ++i) {
+                if (shapes[i].geo != RTC_GEO_SPHERE || !centre_ok(i)) continue;
+                const double c[3] = {shapes[i].transform[3], shapes[i].transform[7], shapes[i].transform[11]};
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = any ? std::fmin(lo[a], c[a]) : c[a];
+                    hi[a] = any ? std::fmax(hi[a], c[a]) : c[a];
+                }
+                any = true;
+            }
+            auto morton = [&](uint64_t i) -> uint64_t {
+                if (!centre_ok(i)) return 0;
+                const double c[3] = {shapes[i].transform[3], shapes[i].transform[7], shapes[i].transform[11]};
+                uint64_t key = 0;
+                uint32_t q[3];
+                for (int a = 0; a < 3; ++a) {
+                    const double span = hi[a] - lo[a];
+                    double f = span > 0 && std::isfinite(span) ? (c[a] - lo[a]) / span : 0.0;
+                    f = f < 0 ? 0 : (f > 1 ? 1 : f);
+                    q[a] = (uint32_t)(f * 1048575.0);  // 20 bits per axis
+                }
+                for (int bit = 19; bit >= 0; --bit)
+                    for (int a = 0; a < 3; ++a) key = (key << 1) | ((q[a] >> bit) & 1u);
+                return key;
+            };
+            for (int g = 0; g < rtc::kSweepGroups; ++g) {
+                if (rtc::kSweepGroupTable[g].geo != RTC_GEO_SPHERE) continue;
+                std::vector<std::pair<uint64_t, uint64_t>> keyed;
+                keyed.reserve(members[g].size());
+                for (uint64_t i : members[g]) keyed.push_back({morton(i), i});
+                std::sort(keyed.begin(), keyed.end());  // (ties by list index: deterministic)
+                for (size_t k = 0; k < keyed.size(); ++k) members[g][k] = keyed[k].second;
+            }
+        }
         for (int g = 0; g < rtc::kSweepGroups; ++g) {
             group[g] = (int32_t)pos;
-            for (uint64_t i = 0; i < n_shapes; ++i) {
-                if (group_of[i] != g) continue;
+            for (uint64_t i : members[g]) {
                 // the record of the shape in its group's layout (rtc_internal.h: kRec*), what each kind of sweep
                 // reads side by side so that it arrives with one or two scalar loads
                 const double* m = &inv12[i * 12];
@@ -1202,6 +1303,51 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
             for (int k = 0; k < 4; ++k) {
                 pairs[q * 8 + 2 * k + half] = rad[k];
                 pairs[sc->sphere_pairs_floats + q * 8 + 2 * k + half] = sha[k];
+            }
+        }
+        // the block tests' tables behind them: per block of kSphereBlock consecutive spheres a bounding sphere of
+        // the members' bounding spheres, two blocks per record of 8 floats, padded like the tables above
+        {
+            const size_t n_blocks = (n_sph + rtc::kSphereBlock - 1) / rtc::kSphereBlock;
+            std::vector<const RtcScene::SphereBound*> by_pos(n_sph, nullptr);
+            for (const RtcScene::SphereBound& sb : sc->sphere_bounds) by_pos[(size_t)sb.pos] = &sb;
+            std::vector<BlockBound> blocks(n_blocks);
+            double eps_blocks = 0.0;  // the largest shrink any block asks for
+            for (size_t b = 0; b < n_blocks; ++b) {
+                const size_t first = b * rtc::kSphereBlock, last = std::min(n_sph, first + rtc::kSphereBlock);
+                blocks[b] = sphere_block_bound(&by_pos[first], last - first);
+                if (blocks[b].bounded) eps_blocks = std::fmax(eps_blocks, blocks[b].eps);
+            }
+            // one shrink for the whole scene (a larger one only makes a test more cautious); beyond 2^-12 the
+            // blocks of this scene are too loose to be worth a test
+            const bool usable = eps_blocks > 0 && eps_blocks <= 0x1p-12;
+            sc->block_shrink = usable ? (1.0 - eps_blocks) / (1.0 - 0x1p-27) : 0.0;
+            sc->block_margin_scale = usable ? eps_blocks / 0x1p-27 : 1.0;
+            const size_t n_records = (n_blocks + 1) / 2 + rtc::kSphereBoundsPadding / 16 + 8;
+            const size_t table_floats = n_records * 8;
+            const size_t base = pairs.size();
+            sc->block_pairs_offset_radiance = (uint32_t)(base - 0);
+            sc->block_pairs_offset_shadow = (uint32_t)(base + table_floats - sc->sphere_pairs_floats);
+            pairs.resize(base + 2 * table_floats, 0.0f);
+            for (size_t q = 0; q < n_records; ++q) {
+                pairs[base + q * 8 + 6] = pairs[base + q * 8 + 7] = -std::numeric_limits<float>::infinity();
+                pairs[base + table_floats + q * 8 + 6] = pairs[base + table_floats + q * 8 + 7] = std::numeric_limits<float>::infinity();
+            }
+            for (size_t b = 0; b < n_blocks; ++b) {
+                float rad[4] = {0, 0, 0, std::numeric_limits<float>::infinity()}, sha[4] = {0, 0, 0, -std::numeric_limits<float>::infinity()};
+                if (usable && blocks[b].bounded) {
+                    // the block's sphere as sphere_bound would store it, with the scene's shrink
+                    double bound[4] = {blocks[b].c[0], blocks[b].c[1], blocks[b].c[2],
+                                       std::nextafter(blocks[b].r2 / (1.0 - eps_blocks), std::numeric_limits<double>::infinity())};
+                    double from_light[4];
+                    sphere_from_light(bound, light->position, from_light, eps_blocks);
+                    sphere_prefilter_tables(bound, from_light, rad, sha);
+                }
+                const size_t q = b / 2, half = b % 2;
+                for (int k = 0; k < 4; ++k) {
+                    pairs[base + q * 8 + 2 * k + half] = rad[k];
+                    pairs[base + table_floats + q * 8 + 2 * k + half] = sha[k];
+                }
             }
         }
         SCENE_TRY(hipMalloc((void**)&sc->d_sphere_pairs, pairs.size() * sizeof(float)));

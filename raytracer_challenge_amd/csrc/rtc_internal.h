@@ -39,7 +39,9 @@ constexpr int kRecAxisSphereM = 0, kRecAxisSphereOrder = 6, kRecAxisSphereBr2 = 
 constexpr int kRecAxisPlaneM = 0, kRecAxisPlaneOrder = 2, kRecAxisPlaneLight = 4;
 constexpr int kRecPlaneM = 0, kRecPlaneOrder = 4, kRecPlaneLight = 5;
 constexpr int kRecFullOrder = 12, kRecFullBound = 13, kRecFullLight = 20;
-constexpr int kSphereBoundsPadding = 16;  // entries the streamed sweep may read ahead of the last sphere
+constexpr int kSphereBoundsPadding = 80;  // entries the streamed sweep may read past the last sphere (a block of 64 and the read-ahead)
+constexpr int kLdsShapeLimit = 32;        // worlds of at most this many shapes keep their per-hit tables in LDS
+constexpr int kSphereBlock = 8;           // spheres per block of the streamed sweep's block test
 constexpr int kRecordDoubles = 24;  // doubles per sweep-table record (see DevWorld)
 
 // The sweep table is grouped by kind of test: one row per group, in table order.  A shape kind
@@ -125,6 +127,14 @@ struct DevWorld {
     // k0 k1), for the packed pre-test of the streamed sweep (sphere_prefilter_tables, rtc_api.hip)
     const float* sphere_pairs_radiance;
     const float* sphere_pairs_shadow;
+    // Behind each of the two: the same test for BLOCKS of kSphereBlock spheres that follow each other in the table
+    // (large worlds keep their spheres in Morton order of their centres, so a block is a cluster): one record of 8
+    // floats per two blocks, holding a sphere around the block's bounding spheres (sphere_block_bound, rtc_api.hip).
+    // A ray that clears it clears every sphere of the block.  Offsets in floats from the two pointers above;
+    // block_shrink scales the ray's |d|^2 term for these tests, block_margin_scale the shadow ray's margin
+    // (block_shrink == 0: the block tests dismiss nothing).
+    uint32_t block_pairs_offset_radiance, block_pairs_offset_shadow;
+    double block_shrink, block_margin_scale;
     int32_t n;
     int32_t group[kSweepGroups + 1];
     // acceleration (rtc_scene_set_acceleration): nullptr = every sphere is tested (the reference's list walk)

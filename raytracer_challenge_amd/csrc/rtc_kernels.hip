@@ -665,10 +665,19 @@ template <bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_spheres_streamed(const float* __restrict__ pairs, const double* __restrict__ bounds,
                                                        const double* __restrict__ tab, const int* __restrict__ order_of,
                                                        int begin, int split, int end, const V3& o, const V3& d, double dd,
-                                                       double shadow_margin, Sweep& s, ContainerSlots& cs,
+                                                       double shadow_margin, uint32_t block_pairs_offset, double block_shrink,
+                                                       double block_margin_scale, Sweep& s, ContainerSlots& cs,
                                                        SweepCounters& ctr) {
     if (begin >= end) return;
     const Ray32 r32 = ray_in_floats<SHADOW>(o, d, dd, shadow_margin);
+    // the same ray for the block tests: their shrink in the |d|^2 term, their larger per-ray margin for shadow rays
+    Ray32 r32b = r32;
+    {
+        const Ray32 t = ray_in_floats<SHADOW>(o, d, dd * block_shrink, shadow_margin * block_margin_scale);
+        r32b.a = t.a;
+        r32b.b = t.b;
+        if (SHADOW && !(block_shrink > 0.0)) r32b.a = {__builtin_huge_valf(), __builtin_huge_valf()};  // dismisses nothing
+    }
     // what the float test could not dismiss: the double test on the sphere's four operands (fetched now), then,
     // for the lanes that fail it too, the full test on the sphere's record
     auto rest = [&](int i, bool clear32) {
@@ -709,15 +718,45 @@ __device__ __forceinline__ void sweep_spheres_streamed(const float* __restrict__
             rest(i + 7, c7);
         }
     };
+    // Blocks first: 64 spheres = eight blocks = four records of the block table per trip, one trip read ahead; the
+    // spheres of a block are looked at (their own records fetched then) only by lanes that cannot dismiss the block.
+    // (begin is the start of the table: blocks are counted from there.)
+    static_assert(kSphereBlock == 8, "one call of eight() per block");
     const float* __restrict__ p = pairs + (size_t)begin * 4;
-    Pairs4 A = load_pairs4(p);
-    for (int i = begin; i < end; i += 16, p += 64) {
-        asm volatile("" ::"s"(A.v[31]) : "memory");
-        const Pairs4 B = load_pairs4(p + 32);
-        eight(A.v, i);
-        asm volatile("" ::"s"(B.v[31]) : "memory");
-        A = load_pairs4(p + 64);
-        eight(B.v, i + 8);
+    const float* __restrict__ g = pairs + block_pairs_offset;
+    Pairs4 G = load_pairs4(g);
+    for (int i = begin; i < end; i += 8 * kSphereBlock, p += 32 * kSphereBlock, g += 32) {
+        asm volatile("" ::"s"(G.v[31]) : "memory");
+        const Pairs4 N = load_pairs4(g + 32);
+        bool b0, b1, b2, b3, b4, b5, b6, b7;
+        pair_clear<SHADOW>(G.v, r32b, b0, b1);
+        pair_clear<SHADOW>(G.v + 8, r32b, b2, b3);
+        pair_clear<SHADOW>(G.v + 16, r32b, b4, b5);
+        pair_clear<SHADOW>(G.v + 24, r32b, b6, b7);
+        // which blocks this lane cannot dismiss, as a bit mask; the loop below visits the blocks some lane
+        // needs (one copy of the per-sphere code, not eight)
+        const uint32_t need = (b0 ? 0u : 1u) | (b1 ? 0u : 2u) | (b2 ? 0u : 4u) | (b3 ? 0u : 8u) | (b4 ? 0u : 16u) |
+                              (b5 ? 0u : 32u) | (b6 ? 0u : 64u) | (b7 ? 0u : 128u);
+        uint32_t wave_needs = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wave_needs |= __ballot((need >> q) & 1u) != 0 ? 1u << q : 0u;
+        if (STATS) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int first = i + q * kSphereBlock;
+                if (first < end && !((need >> q) & 1u))
+                    ctr.sphere_prefilter_skips += (uint32_t)(end - first < kSphereBlock ? end - first : kSphereBlock);
+            }
+        }
+#pragma unroll 1
+        for (uint32_t left = wave_needs; left != 0; left &= left - 1u) {
+            const int q = __ffs((int)left) - 1;
+            const int first = i + q * kSphereBlock;
+            if (first >= end) break;
+            const Pairs4 S = load_pairs4(p + q * 4 * kSphereBlock);
+            if ((need >> q) & 1u) eight(S.v, first);
+        }
+        G = N;
     }
 }
 
@@ -829,7 +868,8 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
         if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, shadow_margin, s, cs, ctr);
     } else if (STREAM) {
         sweep_spheres_streamed<SHADOW, STATS>(sphere_pairs, sphere_bounds, tab, order_of, w.group[0], w.group[1], w.group[2], o, d, dd,
-                                              shadow_margin, s, cs, ctr);
+                                              shadow_margin, SHADOW ? w.block_pairs_offset_shadow : w.block_pairs_offset_radiance,
+                                              w.block_shrink, w.block_margin_scale, s, cs, ctr);
     } else {
         sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
         sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
