@@ -623,18 +623,19 @@ def main():
             }
         if st.sphere_prefilter_skips:
             # a world too large for the on-chip tables: nearly every ray-sphere pair ends in the packed
-            # single-precision pre-test, which the FP64 figures above do not see.  Per pair it costs 17
-            # single-precision flops for a radiance ray (difference 3, two dot products 5 + 5, margin 2,
-            # two products 2) and 7 for a shadow ray (dot product 5, margin 1, square 1).
+            # single-precision pre-tests (first per block of eight spheres, then per sphere of the blocks that
+            # some lane of the wave cannot dismiss), which the FP64 figures above do not see.  A test costs 17
+            # single-precision flops for a radiance ray (difference 3, two dot products 5 + 5, margin 2, two
+            # products 2) and 7 for a shadow ray (dot product 5, margin 1, square 1).  Counted here: the block
+            # tests only (the per-sphere tests that follow depend on how alike the rays of a wave are).
             groups_now = scene.group_counts()
             n_sph = sum(n for n, g in zip(groups_now, group_table) if g["geo"] == 0)
-            f32 = (st.radiance_rays * 17 + st.shadow_rays * 7) * n_sph
-            roofline["bound"] = "valu-issue (packed f32 pre-test + f64)"
-            roofline["f32_prefilter_flops_per_launch"] = f32
-            roofline["f32_prefilter_achieved_tflops"] = f32 / sec / 1e12
-            roofline["f32_packed_peak_tflops_no_fma"] = 2 * PEAK_FP64_NO_FMA_TFLOPS
-            roofline["pairs_dismissed_by_f32_pre_test"] = st.sphere_prefilter_skips / max(st.sphere_tests, 1)
-            roofline["note"] += (". In this workload the single-precision pre-test dismisses most ray-sphere pairs "
+            n_blocks = (n_sph + 7) // 8
+            f32 = (st.radiance_rays * 17 + st.shadow_rays * 7) * n_blocks
+            roofline["bound"] = "valu-issue (packed f32 pre-tests + f64)"
+            roofline["f32_block_test_flops_per_launch"] = f32
+            roofline["pairs_dismissed_by_f32_pre_tests"] = st.sphere_prefilter_skips / max(st.sphere_tests, 1)
+            roofline["note"] += (". In this workload the single-precision pre-tests dismiss most ray-sphere pairs "
                                  "before any FP64 operation: `frac` (FP64 flops only) is then no measure of how busy "
                                  "the vector units are; `counter_check.valu_busy` is")
             if "counter_check" in roofline:
