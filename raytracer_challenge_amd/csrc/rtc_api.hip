@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <mutex>
 #include <new>
@@ -722,8 +723,8 @@ void sphere_from_light(const double* bound, const double* light_pos, double out[
 // (expand both sides: the difference is delta (z / R - 2 (sqrt(R^2 + z) - R)) >= 0).  So with
 //     rho_i = sqrt(b_i + 2 eps delta_i^2) ,   R >= delta_i + rho_i for every member ,   eps_B >= 2 eps R / rho_i ,
 // the block's test D^2 > R^2 + eps_B |C - o|^2 gives (D - delta_i)^2 > rho_i^2 + 2 eps |C - o|^2, which is the
-// line above.  Roundings of this function are covered by the factors 1 + 2^-40; the centre is the mean of
-// the members' centres (any point would do).  A member without a bound leaves the block without one.
+// line above.  Roundings of this function are covered by the factors 1 + 2^-40; the centre starts as the mean of
+// the members' centres and is moved towards the centre of their smallest enclosing ball (any point would do).  A member without a bound leaves the block without one.
 struct BlockBound {
     bool bounded = false;
     double c[3] = {0, 0, 0};
@@ -739,6 +740,32 @@ BlockBound sphere_block_bound(const RtcScene::SphereBound* const* members, size_
         for (int a = 0; a < 3; ++a) c[a] += members[k]->b[a] / (double)n;
     }
     const double eps = 0x1p-27, up = 1.0 + 0x1p-40;
+    {
+        // a better centre than the mean: a few steps towards the member that reaches farthest, each shorter than
+        // the one before (the iteration of Badoiu and Clarkson for the smallest enclosing ball); the centre that
+        // gave the smallest radius is kept.  Only the quality of the bound depends on it.
+        auto reach = [&](const double* at, size_t* farthest) {
+            double worst = -1.0;
+            for (size_t k = 0; k < n; ++k) {
+                double d2 = 0;
+                for (int a = 0; a < 3; ++a) d2 += (members[k]->b[a] - at[a]) * (members[k]->b[a] - at[a]);
+                const double r = std::sqrt(d2) + std::sqrt(members[k]->b[3]);
+                if (r > worst) worst = r, *farthest = k;
+            }
+            return worst;
+        };
+        double at[3] = {c[0], c[1], c[2]};
+        size_t far = 0;
+        double best = reach(at, &far);
+        for (int step = 1; step <= 48 && std::isfinite(best); ++step) {
+            for (int a = 0; a < 3; ++a) at[a] += (members[far]->b[a] - at[a]) / (double)(step + 1);
+            const double r = reach(at, &far);
+            if (r < best) {
+                best = r;
+                for (int a = 0; a < 3; ++a) c[a] = at[a];
+            }
+        }
+    }
     double R = 0, rho_min = std::numeric_limits<double>::infinity();
     for (size_t k = 0; k < n; ++k) {
         double d2 = 0;
@@ -1132,50 +1159,58 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     {
         size_t pos = 0;
         // Members of every group in list order; in a world too large for the on-chip tables the spheres of a
-        // group follow the Morton order of their centres instead, so that spheres that follow each other in the
+        // group follow a spatial order of their centres instead, so that spheres that follow each other in the
         // table lie close together and the streamed sweep can dismiss them a block at a time (sphere_block_bound).
         // Nothing depends on the order inside a group: equal t are resolved by the list index kept with each record.
         std::vector<std::vector<uint64_t>> members(rtc::kSweepGroups);
         for (uint64_t i = 0; i < n_shapes; ++i)
             if (group_of[i] >= 0) members[group_of[i]].push_back(i);
         if (n_shapes > (uint64_t)rtc::kLdsShapeLimit) {
-            double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-            bool any = false;
             auto centre_ok = [&](uint64_t i) {
                 const double* t = shapes[i].transform;
                 return std::isfinite(t[3]) && std::isfinite(t[7]) && std::isfinite(t[11]);
             };
-            for (uint64_t i = 0; i < n_shapes; ++i) {
-                if (shapes[i].geo != RTC_GEO_SPHERE || !centre_ok(i)) continue;
-                const double c[3] = {shapes[i].transform[3], shapes[i].transform[7], shapes[i].transform[11]};
-                for (int a = 0; a < 3; ++a) {
-                    lo[a] = any ? std::fmin(lo[a], c[a]) : c[a];
-                    hi[a] = any ? std::fmax(hi[a], c[a]) : c[a];
-                }
-                any = true;
-            }
-            auto morton = [&](uint64_t i) -> uint64_t {
-                if (!centre_ok(i)) return 0;
-                const double c[3] = {shapes[i].transform[3], shapes[i].transform[7], shapes[i].transform[11]};
-                uint64_t key = 0;
-                uint32_t q[3];
-                for (int a = 0; a < 3; ++a) {
-                    const double span = hi[a] - lo[a];
-                    double f = span > 0 && std::isfinite(span) ? (c[a] - lo[a]) / span : 0.0;
-                    f = f < 0 ? 0 : (f > 1 ? 1 : f);
-                    q[a] = (uint32_t)(f * 1048575.0);  // 20 bits per axis
-                }
-                for (int bit = 19; bit >= 0; --bit)
-                    for (int a = 0; a < 3; ++a) key = (key << 1) | ((q[a] >> bit) & 1u);
-                return key;
+            // Spatial order by recursive median split: the range is cut across the axis along which its centres
+            // spread most, at a table position that is a multiple of the block size (of eight blocks while the range
+            // is longer than that), so that every block - and every run of eight blocks - is one cell of the split:
+            // compact clusters, whose bounding spheres few rays cross.  (Shapes without a finite centre go last.)
+            auto centre = [&](uint64_t i, int a) -> double { return shapes[i].transform[3 + 4 * a]; };
+            size_t table_pos = 0;  // where the group starts in the table: blocks are counted from position 0
+            std::function<void(std::vector<uint64_t>&, size_t, size_t)> split = [&](std::vector<uint64_t>& v, size_t lo_i, size_t hi_i) {
+                const size_t n_here = hi_i - lo_i;
+                if (n_here <= (size_t)rtc::kSphereBlock) return;
+                const size_t unit = n_here > 8u * rtc::kSphereBlock ? 8u * rtc::kSphereBlock : (size_t)rtc::kSphereBlock;
+                // absolute table position of the cut: the multiple of `unit` nearest the middle, inside the range
+                const size_t abs_lo = table_pos + lo_i, abs_hi = table_pos + hi_i;
+                size_t cut = ((abs_lo + abs_hi) / 2 + unit / 2) / unit * unit;
+                if (cut <= abs_lo) cut += unit;
+                if (cut >= abs_hi) cut -= unit;
+                if (cut <= abs_lo || cut >= abs_hi) return;  // the range lies inside one unit
+                double lo_c[3], hi_c[3];
+                for (int a = 0; a < 3; ++a) lo_c[a] = hi_c[a] = centre(v[lo_i], a);
+                for (size_t k = lo_i; k < hi_i; ++k)
+                    for (int a = 0; a < 3; ++a) {
+                        lo_c[a] = std::fmin(lo_c[a], centre(v[k], a));
+                        hi_c[a] = std::fmax(hi_c[a], centre(v[k], a));
+                    }
+                int axis = 0;
+                for (int a = 1; a < 3; ++a)
+                    if (hi_c[a] - lo_c[a] > hi_c[axis] - lo_c[axis]) axis = a;
+                const size_t mid = cut - table_pos;
+                std::nth_element(v.begin() + lo_i, v.begin() + mid, v.begin() + hi_i, [&](uint64_t x, uint64_t y) {
+                    const double cx = centre(x, axis), cy = centre(y, axis);
+                    return cx < cy || (cx == cy && x < y);  // (ties by list index: deterministic)
+                });
+                split(v, lo_i, mid);
+                split(v, mid, hi_i);
             };
             for (int g = 0; g < rtc::kSweepGroups; ++g) {
-                if (rtc::kSweepGroupTable[g].geo != RTC_GEO_SPHERE) continue;
-                std::vector<std::pair<uint64_t, uint64_t>> keyed;
-                keyed.reserve(members[g].size());
-                for (uint64_t i : members[g]) keyed.push_back({morton(i), i});
-                std::sort(keyed.begin(), keyed.end());  // (ties by list index: deterministic)
-                for (size_t k = 0; k < keyed.size(); ++k) members[g][k] = keyed[k].second;
+                if (rtc::kSweepGroupTable[g].geo == RTC_GEO_SPHERE) {
+                    std::vector<uint64_t>& v = members[g];
+                    const size_t n_finite = std::stable_partition(v.begin(), v.end(), centre_ok) - v.begin();
+                    split(v, 0, n_finite);
+                }
+                table_pos += members[g].size();
             }
         }
         for (int g = 0; g < rtc::kSweepGroups; ++g) {
