@@ -190,6 +190,7 @@ struct RtcScene {
     float* d_sphere_pairs = nullptr;    // single-precision pre-test tables: radiance, then shadow (see DevWorld)
     size_t sphere_pairs_floats = 0;     // floats per table
     uint32_t block_pairs_offset_radiance = 0, block_pairs_offset_shadow = 0;  // see DevWorld
+    uint32_t super_pairs_offset_radiance = 0, super_pairs_offset_shadow = 0;
     double block_shrink = 0.0, block_margin_scale = 1.0;
     double* d_sphere_bounds = nullptr;  // radiance table, then shadow table (see DevWorld)
     size_t sphere_bounds_doubles = 0;   // doubles per table
@@ -266,6 +267,8 @@ rtc::DevWorld dev_world(const RtcScene* s) {
     w.sphere_pairs_shadow = s->d_sphere_pairs ? s->d_sphere_pairs + s->sphere_pairs_floats : nullptr;
     w.block_pairs_offset_radiance = s->block_pairs_offset_radiance;
     w.block_pairs_offset_shadow = s->block_pairs_offset_shadow;
+    w.super_pairs_offset_radiance = s->super_pairs_offset_radiance;
+    w.super_pairs_offset_shadow = s->super_pairs_offset_shadow;
     w.block_shrink = s->block_shrink;
     w.block_margin_scale = s->block_margin_scale;
     w.sphere_bounds_radiance = s->d_sphere_bounds;
@@ -1341,49 +1344,58 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
             }
         }
         // the block tests' tables behind them: per block of kSphereBlock consecutive spheres a bounding sphere of
-        // the members' bounding spheres, two blocks per record of 8 floats, padded like the tables above
+        // the members' bounding spheres, two blocks per record of 8 floats, padded like the tables above; and behind
+        // those the same per super-block (eight blocks = 64 consecutive spheres)
         {
-            const size_t n_blocks = (n_sph + rtc::kSphereBlock - 1) / rtc::kSphereBlock;
             std::vector<const RtcScene::SphereBound*> by_pos(n_sph, nullptr);
             for (const RtcScene::SphereBound& sb : sc->sphere_bounds) by_pos[(size_t)sb.pos] = &sb;
-            std::vector<BlockBound> blocks(n_blocks);
-            double eps_blocks = 0.0;  // the largest shrink any block asks for
-            for (size_t b = 0; b < n_blocks; ++b) {
-                const size_t first = b * rtc::kSphereBlock, last = std::min(n_sph, first + rtc::kSphereBlock);
-                blocks[b] = sphere_block_bound(&by_pos[first], last - first);
-                if (blocks[b].bounded) eps_blocks = std::fmax(eps_blocks, blocks[b].eps);
-            }
+            double eps_blocks = 0.0;  // the largest shrink any block or super-block asks for
+            auto bounds_of = [&](size_t unit) {
+                std::vector<BlockBound> v((n_sph + unit - 1) / unit);
+                for (size_t b = 0; b < v.size(); ++b) {
+                    const size_t first = b * unit, last = std::min(n_sph, first + unit);
+                    v[b] = sphere_block_bound(&by_pos[first], last - first);
+                    if (v[b].bounded) eps_blocks = std::fmax(eps_blocks, v[b].eps);
+                }
+                return v;
+            };
+            const std::vector<BlockBound> blocks = bounds_of(rtc::kSphereBlock), supers = bounds_of(8 * rtc::kSphereBlock);
             // one shrink for the whole scene (a larger one only makes a test more cautious); beyond 2^-12 the
             // blocks of this scene are too loose to be worth a test
             const bool usable = eps_blocks > 0 && eps_blocks <= 0x1p-12;
             sc->block_shrink = usable ? (1.0 - eps_blocks) / (1.0 - 0x1p-27) : 0.0;
             sc->block_margin_scale = usable ? eps_blocks / 0x1p-27 : 1.0;
-            const size_t n_records = (n_blocks + 1) / 2 + rtc::kSphereBoundsPadding / 16 + 8;
-            const size_t table_floats = n_records * 8;
-            const size_t base = pairs.size();
-            sc->block_pairs_offset_radiance = (uint32_t)(base - 0);
-            sc->block_pairs_offset_shadow = (uint32_t)(base + table_floats - sc->sphere_pairs_floats);
-            pairs.resize(base + 2 * table_floats, 0.0f);
-            for (size_t q = 0; q < n_records; ++q) {
-                pairs[base + q * 8 + 6] = pairs[base + q * 8 + 7] = -std::numeric_limits<float>::infinity();
-                pairs[base + table_floats + q * 8 + 6] = pairs[base + table_floats + q * 8 + 7] = std::numeric_limits<float>::infinity();
-            }
-            for (size_t b = 0; b < n_blocks; ++b) {
-                float rad[4] = {0, 0, 0, std::numeric_limits<float>::infinity()}, sha[4] = {0, 0, 0, -std::numeric_limits<float>::infinity()};
-                if (usable && blocks[b].bounded) {
-                    // the block's sphere as sphere_bound would store it, with the scene's shrink
-                    double bound[4] = {blocks[b].c[0], blocks[b].c[1], blocks[b].c[2],
-                                       std::nextafter(blocks[b].r2 / (1.0 - eps_blocks), std::numeric_limits<double>::infinity())};
-                    double from_light[4];
-                    sphere_from_light(bound, light->position, from_light, eps_blocks);
-                    sphere_prefilter_tables(bound, from_light, rad, sha);
+            // appends the radiance and the shadow table of one level; returns where the radiance table starts
+            auto append_level = [&](const std::vector<BlockBound>& level, uint32_t* offset_radiance, uint32_t* offset_shadow) {
+                const size_t n_records = (level.size() + 1) / 2 + rtc::kSphereBoundsPadding / 16 + 8;
+                const size_t table_floats = n_records * 8;
+                const size_t base = pairs.size();
+                *offset_radiance = (uint32_t)(base - 0);
+                *offset_shadow = (uint32_t)(base + table_floats - sc->sphere_pairs_floats);
+                pairs.resize(base + 2 * table_floats, 0.0f);
+                for (size_t q = 0; q < n_records; ++q) {
+                    pairs[base + q * 8 + 6] = pairs[base + q * 8 + 7] = -std::numeric_limits<float>::infinity();
+                    pairs[base + table_floats + q * 8 + 6] = pairs[base + table_floats + q * 8 + 7] = std::numeric_limits<float>::infinity();
                 }
-                const size_t q = b / 2, half = b % 2;
-                for (int k = 0; k < 4; ++k) {
-                    pairs[base + q * 8 + 2 * k + half] = rad[k];
-                    pairs[base + table_floats + q * 8 + 2 * k + half] = sha[k];
+                for (size_t b = 0; b < level.size(); ++b) {
+                    float rad[4] = {0, 0, 0, std::numeric_limits<float>::infinity()}, sha[4] = {0, 0, 0, -std::numeric_limits<float>::infinity()};
+                    if (usable && level[b].bounded) {
+                        // the block's sphere as sphere_bound would store it, with the scene's shrink
+                        double bound[4] = {level[b].c[0], level[b].c[1], level[b].c[2],
+                                           std::nextafter(level[b].r2 / (1.0 - eps_blocks), std::numeric_limits<double>::infinity())};
+                        double from_light[4];
+                        sphere_from_light(bound, light->position, from_light, eps_blocks);
+                        sphere_prefilter_tables(bound, from_light, rad, sha);
+                    }
+                    const size_t q = b / 2, half = b % 2;
+                    for (int k = 0; k < 4; ++k) {
+                        pairs[base + q * 8 + 2 * k + half] = rad[k];
+                        pairs[base + table_floats + q * 8 + 2 * k + half] = sha[k];
+                    }
                 }
-            }
+            };
+            append_level(blocks, &sc->block_pairs_offset_radiance, &sc->block_pairs_offset_shadow);
+            append_level(supers, &sc->super_pairs_offset_radiance, &sc->super_pairs_offset_shadow);
         }
         SCENE_TRY(hipMalloc((void**)&sc->d_sphere_pairs, pairs.size() * sizeof(float)));
         SCENE_TRY(hipMemcpy(sc->d_sphere_pairs, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));

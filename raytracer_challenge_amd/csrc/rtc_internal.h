@@ -134,6 +134,9 @@ struct DevWorld {
     // block_shrink scales the ray's |d|^2 term for these tests, block_margin_scale the shadow ray's margin
     // (block_shrink == 0: the block tests dismiss nothing).
     uint32_t block_pairs_offset_radiance, block_pairs_offset_shadow;
+    // and behind those, in the same format, one entry per SUPER-BLOCK: eight blocks that follow each other in the
+    // table (64 spheres; the table order is a spatial one, so they are a cluster too), with the same shrink
+    uint32_t super_pairs_offset_radiance, super_pairs_offset_shadow;
     double block_shrink, block_margin_scale;
     int32_t n;
     int32_t group[kSweepGroups + 1];

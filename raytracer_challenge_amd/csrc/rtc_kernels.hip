@@ -760,111 +760,149 @@ __device__ __forceinline__ void sweep_spheres_streamed(const float* __restrict__
     }
 }
 
-// The same sweep with the blocks' members tested per lane.  After a few bounces the rays of a wave have little in
-// common: nearly every block is needed by SOME lane, so testing a needed block's members wave-wide (above) runs the
-// member tests for the union of what 64 rays need, most of the wave masked off.  Here only the block tests stay
-// wave-uniform (scalar loads of the block table, one packed test per two blocks).  Each lane notes the blocks it
-// cannot dismiss as bits of a 64-bit word (a window of 64 blocks = 512 spheres); at the end of a window every lane
-// works off its own bits: the block's eight spheres fetched with per-lane vector loads from the same tables, the
-// same packed single-precision test, then for the survivors the double test and the sphere's full test on rows 0..2
-// of its inverse (the per-hit inverse table holds them for every sphere; a diagonal inverse's products with its
-// exact zeros add nothing).  A trip of the drain loop serves a different block in every lane, so the loop runs as
-// long as the busiest lane's list, not as long as the union.  What is evaluated for a (ray, sphere) pair that
-// reaches the full test is what sweep_shape evaluates; which pairs are dismissed before is decided by the same
-// tests on the same operands.  A shadow ray that has found an occluder needs nothing more (calc.zig:789 only asks
-// whether one exists); the statistics build goes on, to count what the reference intersects.
+// The same sweep with per-lane work lists.  After a few bounces the rays of a wave have little in common: nearly
+// every block is needed by SOME lane, so testing a needed block's members wave-wide (above) runs the member tests
+// for the union of what 64 rays need, most of the wave masked off.  Here only the coarsest tests stay wave-uniform:
+// the table position order is a spatial one (rtc_scene_create), so eight blocks that follow each other - a
+// "super-block" of 64 spheres - are a cluster too and have a bounding sphere of their own in a third table behind
+// the blocks' (same format, same test, same derivation with 64 members).  The super-blocks are tested with scalar
+// loads, one packed test per two; each lane notes the ones it cannot dismiss as bits of a 64-bit word (a window of
+// 64 super-blocks = 4096 spheres).  At the end of a window every lane works off its own list, one item per trip
+// of the drain loop: either a super-block (its eight blocks fetched from the block table with per-lane vector
+// loads and tested; the survivors become the lane's current blocks) or a block (its eight spheres fetched from the
+// pair table and tested; the survivors go on to the double test and then to the sphere's full test on rows 0..2 of
+// its inverse - the per-hit inverse table holds them for every sphere; a diagonal inverse's products with its exact
+// zeros add nothing).  Both kinds of item are the same loads and the same four packed tests on different
+// addresses and margins, so lanes at different items run the same instructions.  The loop runs as long as the
+// busiest lane's list, not as long as the union of all lists.  What is evaluated for a (ray, sphere) pair that
+// reaches the full test is what sweep_shape evaluates; every dismissal before it implies the double test's (see
+// sphere_block_bound and sphere_prefilter_tables, rtc_api.hip).  A shadow ray that has found an occluder needs
+// nothing more (calc.zig:789 only asks whether one exists); the statistics build goes on, to count what the
+// reference intersects.
+constexpr int kSuperBlock = 8 * kSphereBlock;  // spheres per super-block
 template <bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pairs, const double* __restrict__ bounds,
                                                     const double* __restrict__ inv, const int* __restrict__ order_of,
                                                     int begin, int end, const V3& o, const V3& d, double dd,
-                                                    double shadow_margin, uint32_t block_pairs_offset, double block_shrink,
+                                                    double shadow_margin, uint32_t block_pairs_offset,
+                                                    uint32_t super_pairs_offset, double block_shrink,
                                                     double block_margin_scale, Sweep& s, ContainerSlots& cs,
                                                     SweepCounters& ctr) {
     if (begin >= end) return;
     const Ray32 r32 = ray_in_floats<SHADOW>(o, d, dd, shadow_margin);
-    Ray32 r32b = r32;
+    // the same ray for the block and super-block tests: their shrink in the |d|^2 term, their larger per-ray
+    // margin for shadow rays (only the two margin terms differ)
+    float2_t a_blocks, b_blocks;
     {
         const Ray32 t = ray_in_floats<SHADOW>(o, d, dd * block_shrink, shadow_margin * block_margin_scale);
-        r32b.a = t.a;
-        r32b.b = t.b;
-        if (SHADOW && !(block_shrink > 0.0)) r32b.a = {__builtin_huge_valf(), __builtin_huge_valf()};  // dismisses nothing
+        a_blocks = t.a;
+        b_blocks = t.b;
+        if (SHADOW && !(block_shrink > 0.0)) a_blocks = {__builtin_huge_valf(), __builtin_huge_valf()};  // dismisses nothing
     }
-    static_assert(kSphereBlock == 8, "eight member bits per block");
-    unsigned long long pending = 0ull;  // per lane: blocks of the current window this ray cannot dismiss
-    // one lane's turn at one of its blocks: the block's first sphere is `first`
-    auto members = [&](int first) {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(pairs + (size_t)first * 4);
+    static_assert(kSphereBlock == 8, "eight member bits per block, eight block bits per super-block");
+    const float* __restrict__ block_table = pairs + block_pairs_offset;
+    unsigned long long pending = 0ull;  // per lane: super-blocks of the current window this ray cannot dismiss
+    uint32_t blocks = 0u;               // per lane: blocks of the super-block in hand this ray cannot dismiss ...
+    int blocks_first = 0;               // ... and the table position of that super-block's first sphere
+    // eight entries (four records of two) at `src` against the ray with margins a, b: bit k set = entry k not dismissed
+    auto eight = [&](const float* __restrict__ src, const float2_t a, const float2_t b) -> uint32_t {
+        const float4* __restrict__ q4 = reinterpret_cast<const float4*>(src);
         float v[32];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float4 q = src[k];
+            const float4 q = q4[k];
             v[4 * k] = q.x, v[4 * k + 1] = q.y, v[4 * k + 2] = q.z, v[4 * k + 3] = q.w;
         }
+        Ray32 r = r32;
+        r.a = a;
+        r.b = b;
         bool c0, c1, c2, c3, c4, c5, c6, c7;
-        pair_clear<SHADOW>(v, r32, c0, c1);
-        pair_clear<SHADOW>(v + 8, r32, c2, c3);
-        pair_clear<SHADOW>(v + 16, r32, c4, c5);
-        pair_clear<SHADOW>(v + 24, r32, c6, c7);
-        const uint32_t real = end - first >= kSphereBlock ? 0xffu : (1u << (end - first)) - 1u;  // (the tables are padded)
-        uint32_t cand = ((c0 ? 0u : 1u) | (c1 ? 0u : 2u) | (c2 ? 0u : 4u) | (c3 ? 0u : 8u) | (c4 ? 0u : 16u) |
-                         (c5 ? 0u : 32u) | (c6 ? 0u : 64u) | (c7 ? 0u : 128u)) & real;
-        if (STATS) ctr.sphere_prefilter_skips += (uint32_t)__popc(real & ~cand);
-        while (cand != 0u) {
-            const int i = first + (__ffs((int)cand) - 1);
-            cand &= cand - 1u;
-            const double* __restrict__ b = bounds + (size_t)i * 4;
-            const double bb[4] = {b[0], b[1], b[2], b[3]};
-            const bool clear = SHADOW ? sphere_clear_of_shadow_ray(bb, bb[3], d, shadow_margin)
-                                      : sphere_clear_of_ray(bb, bb[3], o, d, dd);
-            if (STATS && clear) ++ctr.sphere_skips;
-            if (!clear) {
-                ShapeRec rec;
-                const double* __restrict__ m = inv + (size_t)i * 12;
+        pair_clear<SHADOW>(v, r, c0, c1);
+        pair_clear<SHADOW>(v + 8, r, c2, c3);
+        pair_clear<SHADOW>(v + 16, r, c4, c5);
+        pair_clear<SHADOW>(v + 24, r, c6, c7);
+        return (c0 ? 0u : 1u) | (c1 ? 0u : 2u) | (c2 ? 0u : 4u) | (c3 ? 0u : 8u) | (c4 ? 0u : 16u) | (c5 ? 0u : 32u) |
+               (c6 ? 0u : 64u) | (c7 ? 0u : 128u);
+    };
+    // how many of the eight entries of `unit` spheres each that start at table position `first` exist (the tables are padded)
+    auto real_bits = [&](int first, int unit) -> uint32_t {
+        const int n = (end - first + unit - 1) / unit;
+        return n >= 8 ? 0xffu : (n <= 0 ? 0u : (1u << n) - 1u);
+    };
+    auto count_dismissed = [&](uint32_t dismissed, int first, int unit) {  // statistics build only
 #pragma unroll
-                for (int k = 0; k < 12; ++k) rec.m[k] = m[k];
-                rec.order = order_of[i];
-                sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
-            }
+        for (int q = 0; q < 8; ++q) {
+            const int at = first + q * unit;
+            if (((dismissed >> q) & 1u) && at < end) ctr.sphere_prefilter_skips += (uint32_t)(end - at < unit ? end - at : unit);
         }
     };
     auto drain = [&](int window_first) {
         for (;;) {
-            if (SHADOW && !STATS && s.idx >= 0) pending = 0ull;
-            if (__ballot(pending != 0ull) == 0ull) break;
-            if (pending != 0ull) {
-                const int q = __ffsll((long long)pending) - 1;
-                pending &= pending - 1ull;
-                members(window_first + q * kSphereBlock);
+            if (SHADOW && !STATS && s.idx >= 0) pending = 0ull, blocks = 0u;
+            if (__ballot((pending | blocks) != 0ull) == 0ull) break;
+            if ((pending | blocks) != 0ull) {
+                const bool is_block = blocks != 0u;
+                int first;  // table position of the first sphere of the item
+                if (is_block) {
+                    first = blocks_first + (__ffs((int)blocks) - 1) * kSphereBlock;
+                    blocks &= blocks - 1u;
+                } else {
+                    first = window_first + (__ffsll((long long)pending) - 1) * kSuperBlock;
+                    pending &= pending - 1ull;
+                }
+                // a block's spheres: 4 floats each from `pairs`; a super-block's blocks: 4 floats each from the block table
+                const float* __restrict__ src = is_block ? pairs + (size_t)first * 4 : block_table + (size_t)(first / kSphereBlock) * 4;
+                const uint32_t real = real_bits(first, is_block ? 1 : kSphereBlock);
+                const uint32_t open = eight(src, is_block ? r32.a : a_blocks, is_block ? r32.b : b_blocks) & real;
+                if (STATS) count_dismissed(real & ~open, first, is_block ? 1 : kSphereBlock);
+                if (!is_block) {
+                    blocks = open;
+                    blocks_first = first;
+                } else {
+                    uint32_t cand = open;
+                    while (cand != 0u) {
+                        const int i = first + (__ffs((int)cand) - 1);
+                        cand &= cand - 1u;
+                        const double* __restrict__ b = bounds + (size_t)i * 4;
+                        const double bb[4] = {b[0], b[1], b[2], b[3]};
+                        const bool clear = SHADOW ? sphere_clear_of_shadow_ray(bb, bb[3], d, shadow_margin)
+                                                  : sphere_clear_of_ray(bb, bb[3], o, d, dd);
+                        if (STATS && clear) ++ctr.sphere_skips;
+                        if (!clear) {
+                            ShapeRec rec;
+                            const double* __restrict__ m = inv + (size_t)i * 12;
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) rec.m[k] = m[k];
+                            rec.order = order_of[i];
+                            sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                        }
+                    }
+                }
             }
         }
     };
-    const float* __restrict__ g = pairs + block_pairs_offset;
+    Ray32 r32s = r32;
+    r32s.a = a_blocks;
+    r32s.b = b_blocks;
+    const float* __restrict__ g = pairs + super_pairs_offset;
     Pairs4 G = load_pairs4(g);
     int trip = 0;
-    for (int i = begin; i < end; i += 8 * kSphereBlock, g += 32, ++trip) {
+    for (int i = begin; i < end; i += 8 * kSuperBlock, g += 32, ++trip) {
         asm volatile("" ::"s"(G.v[31]) : "memory");
         const Pairs4 N = load_pairs4(g + 32);
         bool b0, b1, b2, b3, b4, b5, b6, b7;
-        pair_clear<SHADOW>(G.v, r32b, b0, b1);
-        pair_clear<SHADOW>(G.v + 8, r32b, b2, b3);
-        pair_clear<SHADOW>(G.v + 16, r32b, b4, b5);
-        pair_clear<SHADOW>(G.v + 24, r32b, b6, b7);
-        const int blocks_here = (end - i + kSphereBlock - 1) / kSphereBlock;  // wave-uniform; the table is padded
-        const uint32_t real = blocks_here >= 8 ? 0xffu : (1u << blocks_here) - 1u;
+        pair_clear<SHADOW>(G.v, r32s, b0, b1);
+        pair_clear<SHADOW>(G.v + 8, r32s, b2, b3);
+        pair_clear<SHADOW>(G.v + 16, r32s, b4, b5);
+        pair_clear<SHADOW>(G.v + 24, r32s, b6, b7);
+        const uint32_t real = real_bits(i, kSuperBlock);  // wave-uniform
         const uint32_t need = ((b0 ? 0u : 1u) | (b1 ? 0u : 2u) | (b2 ? 0u : 4u) | (b3 ? 0u : 8u) | (b4 ? 0u : 16u) |
                                (b5 ? 0u : 32u) | (b6 ? 0u : 64u) | (b7 ? 0u : 128u)) & real;
-        if (STATS) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int first = i + q * kSphereBlock;
-                if (first < end && !((need >> q) & 1u))
-                    ctr.sphere_prefilter_skips += (uint32_t)(end - first < kSphereBlock ? end - first : kSphereBlock);
-            }
-        }
+        if (STATS) count_dismissed(real & ~need, i, kSuperBlock);
         const int slot = trip & 7;
         pending |= (unsigned long long)need << (slot * 8);
-        if (slot == 7 || i + 8 * kSphereBlock >= end) {
-            drain(i - slot * 8 * kSphereBlock);
+        if (slot == 7 || i + 8 * kSuperBlock >= end) {
+            drain(i - slot * 8 * kSuperBlock);
             if (SHADOW && !STATS && __ballot(s.idx < 0) == 0ull) break;  // every ray of the wave has its occluder
         }
         G = N;
@@ -980,7 +1018,8 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     } else if (STREAM) {
 #ifndef RTC_NO_LANE_LISTS
         sweep_spheres_lanes<SHADOW, STATS>(sphere_pairs, sphere_bounds, w.inv, order_of, w.group[0], w.group[2], o, d, dd, shadow_margin,
-                                           SHADOW ? w.block_pairs_offset_shadow : w.block_pairs_offset_radiance, w.block_shrink,
+                                           SHADOW ? w.block_pairs_offset_shadow : w.block_pairs_offset_radiance,
+                                           SHADOW ? w.super_pairs_offset_shadow : w.super_pairs_offset_radiance, w.block_shrink,
                                            w.block_margin_scale, s, cs, ctr);
 #else
         sweep_spheres_streamed<SHADOW, STATS>(sphere_pairs, sphere_bounds, tab, order_of, w.group[0], w.group[1], w.group[2], o, d, dd,
