@@ -796,15 +796,21 @@ BlockBound sphere_block_bound(const RtcScene::SphereBound* const* members, size_
 //  * c, o, d are rounded to float and c - o is rounded again: the computed difference vector is off by at most
 //    2.01 u s, s^2 = sum (|c_j| + |o_j|)^2 <= 2 (|c|^2 + |o|^2); its squared length, three more rounded
 //    operations, is off by at most 7.2 u s^2 < 2^-20 (|c|^2 + |o|^2); its product with d by beta = 6.1 u s |d|.
-//  * B^2 <= (1 + 2^-10) B~^2 + (1 + 2^10) beta^2, and the second term is below 2^-31 (|c|^2 + |o|^2) D k.
-//  * The two subtractions that form the left side add 4.1 u (|c|^2 + |o|^2).  In all at most
-//    2^-19.5 (|c|^2 + |o|^2) is lost on the left: the sphere's share, 2^-19.5 |c|^2, is added to its radius
-//    term here (rounded up), the ray's share is subtracted on the device (rounded up).
-//  * The factor 1 + 2^-10 and the rounding of the two final products are covered by scaling D k by 1 - 2^-9
-//    (rounded down) on the device.
-// Shadow rays: lc~.d~ is off by at most 5.2 u |lc| (|d| = 1 to 2^-50), so (lc.d)^2 <= (1 + 2^-10) (lc~.d~)^2 +
-// 2^-33 |lc|^2; the stored term is (lk - 2^-32 |lc|^2)(1 - 2^-8) rounded down, which also covers the rounding
-// of the device's subtraction and product; a term that is not positive can dismiss nothing (-inf).
+//  * B^2 <= (1 + 2^-19) B~^2 + (1 + 2^19) beta^2 (twice the product of two numbers is at most q times the square
+//    of one plus 1/q times the square of the other), and the second term, 2^19 37.2 u^2 s^2 D, is below
+//    0.15 2^-20 (|c|^2 + |o|^2) D k.  The split matters: the factor on B~^2 widens the test by that fraction of
+//    the squared DISTANCE to the sphere, not of its radius - with 2^-10 a sphere of radius 0.6 at distance 60 was
+//    tested as one of radius 2.7.
+//  * The two subtractions that form the left side add 4.1 u (|c|^2 + |o|^2) = 0.26 2^-20 (...).  In all at most
+//    (0.9 + 0.15 + 0.26) 2^-20 < 2^-19.5 times (|c|^2 + |o|^2) is lost on the left: the sphere's share, 2^-19.5
+//    |c|^2, is added to its radius term here (rounded up), the ray's share is subtracted on the device (rounded up).
+//  * The factor 1 + 2^-19 and the rounding of the two final products (a factor (1 + u)/(1 - u) < 1 + 2^-22.9)
+//    are covered by scaling D k by 1 - 2^-18 (rounded down) on the device: (1 - 2^-22.9)/(1 - 2^-18) > 1 + 2^-19.
+// Shadow rays: lc~.d~ is off by at most 5.2 u |lc| (|d| = 1 to 2^-50), so (lc.d)^2 <= (1 + 2^-21) (lc~.d~)^2 +
+// (1 + 2^21) 27.1 u^2 |lc|^2, the last term below 2^-22 |lc|^2; the stored term is (lk - 2^-22 |lc|^2)(1 - 2^-19)
+// rounded down, which also covers the rounding of the device's subtraction and product ((1 - 2^-23)/(1 - 2^-19) >
+// 1 + 2^-21; the per-ray term is subtracted unscaled, which only makes the left side smaller); a term that is
+// not positive can dismiss nothing (-inf).
 // Terms below 2^-100 are raised to it, so that flushed subnormals (at most 2^-126 per operation) stay covered;
 // an overflow gives an infinity or a NaN on the device, and a comparison with either dismisses nothing.
 float float_above(double v) {
@@ -825,7 +831,7 @@ void sphere_prefilter_tables(const double bound[4], const double from_light[4], 
     radiance[3] = (std::isfinite(r) && std::isfinite(cc)) ? std::fmax(float_above(r), 0x1p-100f) : inf;  // +inf: never dismissed
     const double ll = from_light[0] * from_light[0] + from_light[1] * from_light[1] + from_light[2] * from_light[2];
     for (int k = 0; k < 3; ++k) shadow[k] = (float)from_light[k];
-    const double t = (from_light[3] - 0x1p-32 * ll) * (1.0 - 0x1p-8);
+    const double t = (from_light[3] - 0x1p-22 * ll) * (1.0 - 0x1p-19);
     shadow[3] = (std::isfinite(t) && std::isfinite(ll) && t > 0x1p-100) ? float_below(t) : -inf;  // -inf: never dismissed
 }
 

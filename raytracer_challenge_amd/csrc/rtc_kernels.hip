@@ -615,7 +615,7 @@ __device__ __forceinline__ Pairs4 load_pairs4(const float* __restrict__ p) {
     return r;
 }
 // The ray in single precision, each component in both halves of a register pair.  Radiance rays: a = 2^-19.5
-// |o|^2 rounded up (the ray's share of the margin), b = |d|^2 (1 - 2^-27)(1 - 2^-9) rounded down.  Shadow
+// |o|^2 rounded up (the ray's share of the margin), b = |d|^2 (1 - 2^-27)(1 - 2^-18) rounded down.  Shadow
 // rays: a = 2^-25 dist^2 rounded up (the per-ray term of the light-anchored test).
 struct Ray32 {
     float2_t ox, oy, oz, dx, dy, dz, a, b;
@@ -634,7 +634,7 @@ __device__ __forceinline__ Ray32 ray_in_floats(const V3& o, const V3& d, double 
     } else {
         const double oo = fma(o.z, o.z, fma(o.y, o.y, o.x * o.x));
         const float rho = float_up(fmaxf((float)(0x1.6a09e667f3bcdp-20 * oo), 0x1p-100f));
-        const float ds = (float)(dd * (1.0 - 0x1p-9));
+        const float ds = (float)(dd * (1.0 - 0x1p-18));
         const float dsd = ds > 0x1p-100f ? float_down(ds) : 0.0f;  // 0: nothing is dismissed for this ray
         r.a = {rho, rho};
         r.b = {dsd, dsd};
@@ -799,11 +799,13 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         b_blocks = t.b;
         if (SHADOW && !(block_shrink > 0.0)) a_blocks = {__builtin_huge_valf(), __builtin_huge_valf()};  // dismisses nothing
     }
-    static_assert(kSphereBlock == 8, "eight member bits per block, eight block bits per super-block");
+    static_assert(kSphereBlock == 8 && kSuperBlock == 64, "eight member bits per block, eight block bits per super-block; shifts by 3 and 6");
     const float* __restrict__ block_table = pairs + block_pairs_offset;
     unsigned long long pending = 0ull;  // per lane: super-blocks of the current window this ray cannot dismiss
     uint32_t blocks = 0u;               // per lane: blocks of the super-block in hand this ray cannot dismiss ...
     int blocks_first = 0;               // ... and the table position of that super-block's first sphere
+    uint32_t cands = 0u;                // per lane: spheres of the block in hand the packed test could not dismiss ...
+    int cands_first = 0;                // ... and the table position of that block's first sphere
     // eight entries (four records of two) at `src` against the ray with margins a, b: bit k set = entry k not dismissed
     auto eight = [&](const float* __restrict__ src, const float2_t a, const float2_t b) -> uint32_t {
         const float4* __restrict__ q4 = reinterpret_cast<const float4*>(src);
@@ -824,23 +826,60 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         return (c0 ? 0u : 1u) | (c1 ? 0u : 2u) | (c2 ? 0u : 4u) | (c3 ? 0u : 8u) | (c4 ? 0u : 16u) | (c5 ? 0u : 32u) |
                (c6 ? 0u : 64u) | (c7 ? 0u : 128u);
     };
-    // how many of the eight entries of `unit` spheres each that start at table position `first` exist (the tables are padded)
-    auto real_bits = [&](int first, int unit) -> uint32_t {
-        const int n = (end - first + unit - 1) / unit;
-        return n >= 8 ? 0xffu : (n <= 0 ? 0u : (1u << n) - 1u);
+    // (units are powers of two, given by their logarithm: a division by a per-lane value is a long instruction sequence;
+    // first < end for every item)
+    auto real_bits = [&](int first, int unit_log2) -> uint32_t {
+        const uint32_t n = ((uint32_t)(end - first) + (1u << unit_log2) - 1u) >> unit_log2;
+        return n >= 8u ? 0xffu : (1u << n) - 1u;
     };
-    auto count_dismissed = [&](uint32_t dismissed, int first, int unit) {  // statistics build only
+    auto count_dismissed = [&](uint32_t dismissed, int first, int unit_log2) {  // statistics build only
+        const int unit = 1 << unit_log2;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int at = first + q * unit;
             if (((dismissed >> q) & 1u) && at < end) ctr.sphere_prefilter_skips += (uint32_t)(end - at < unit ? end - at : unit);
         }
     };
+    // The work loop.  A lane holds three kinds of work: spheres waiting for the double and the full test (the long,
+    // double-precision part), blocks, and super-blocks.  A trip of the loop does ONE kind for the whole wave, chosen
+    // by a vote, so that the expensive sphere tests run when many lanes have one to do instead of whenever a single
+    // lane does: a lane with spheres waiting takes no further block until they are done.
     auto drain = [&](int window_first) {
         for (;;) {
-            if (SHADOW && !STATS && s.idx >= 0) pending = 0ull, blocks = 0u;
-            if (__ballot((pending | blocks) != 0ull) == 0ull) break;
-            if ((pending | blocks) != 0ull) {
+            if (SHADOW && !STATS && s.idx >= 0) pending = 0ull, blocks = 0u, cands = 0u;
+            const bool has_sphere = cands != 0u;
+            const bool has_eight = !has_sphere && (pending | blocks) != 0ull;
+            const unsigned long long with_sphere = __ballot(has_sphere), with_eight = __ballot(has_eight);
+            if ((with_sphere | with_eight) == 0ull) break;
+#ifdef RTC_NO_SPHERE_VOTE
+            if (has_sphere) {  // (for comparison: every lane does its spheres as soon as it has them)
+                while (cands != 0u) {
+#else
+            if (__popcll(with_sphere) >= __popcll(with_eight)) {
+                if (has_sphere) {
+#endif
+                    const int i = cands_first + (__ffs((int)cands) - 1);
+                    cands &= cands - 1u;
+                    const double* __restrict__ b = bounds + (size_t)(uint32_t)i * 4;
+                    const double bb[4] = {b[0], b[1], b[2], b[3]};
+                    const bool clear = SHADOW ? sphere_clear_of_shadow_ray(bb, bb[3], d, shadow_margin)
+                                              : sphere_clear_of_ray(bb, bb[3], o, d, dd);
+                    if (STATS && clear) ++ctr.sphere_skips;
+                    if (!clear) {
+                        ShapeRec rec;
+                        const double* __restrict__ m = inv + (size_t)(uint32_t)i * 12;
+#pragma unroll
+                        for (int k = 0; k < 12; ++k) rec.m[k] = m[k];
+                        rec.order = order_of[i];
+                        sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                    }
+                }
+            }
+#ifdef RTC_NO_SPHERE_VOTE
+            if (has_eight) {
+#else
+            else if (has_eight) {
+#endif
                 const bool is_block = blocks != 0u;
                 int first;  // table position of the first sphere of the item
                 if (is_block) {
@@ -851,32 +890,16 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                     pending &= pending - 1ull;
                 }
                 // a block's spheres: 4 floats each from `pairs`; a super-block's blocks: 4 floats each from the block table
-                const float* __restrict__ src = is_block ? pairs + (size_t)first * 4 : block_table + (size_t)(first / kSphereBlock) * 4;
-                const uint32_t real = real_bits(first, is_block ? 1 : kSphereBlock);
+                const float* __restrict__ src = is_block ? pairs + (size_t)(uint32_t)first * 4 : block_table + (size_t)((uint32_t)first >> 3) * 4;
+                const uint32_t real = real_bits(first, is_block ? 0 : 3);
                 const uint32_t open = eight(src, is_block ? r32.a : a_blocks, is_block ? r32.b : b_blocks) & real;
-                if (STATS) count_dismissed(real & ~open, first, is_block ? 1 : kSphereBlock);
-                if (!is_block) {
+                if (STATS) count_dismissed(real & ~open, first, is_block ? 0 : 3);
+                if (is_block) {
+                    cands = open;
+                    cands_first = first;
+                } else {
                     blocks = open;
                     blocks_first = first;
-                } else {
-                    uint32_t cand = open;
-                    while (cand != 0u) {
-                        const int i = first + (__ffs((int)cand) - 1);
-                        cand &= cand - 1u;
-                        const double* __restrict__ b = bounds + (size_t)i * 4;
-                        const double bb[4] = {b[0], b[1], b[2], b[3]};
-                        const bool clear = SHADOW ? sphere_clear_of_shadow_ray(bb, bb[3], d, shadow_margin)
-                                                  : sphere_clear_of_ray(bb, bb[3], o, d, dd);
-                        if (STATS && clear) ++ctr.sphere_skips;
-                        if (!clear) {
-                            ShapeRec rec;
-                            const double* __restrict__ m = inv + (size_t)i * 12;
-#pragma unroll
-                            for (int k = 0; k < 12; ++k) rec.m[k] = m[k];
-                            rec.order = order_of[i];
-                            sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
-                        }
-                    }
                 }
             }
         }
@@ -895,10 +918,10 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         pair_clear<SHADOW>(G.v + 8, r32s, b2, b3);
         pair_clear<SHADOW>(G.v + 16, r32s, b4, b5);
         pair_clear<SHADOW>(G.v + 24, r32s, b6, b7);
-        const uint32_t real = real_bits(i, kSuperBlock);  // wave-uniform
+        const uint32_t real = real_bits(i, 6);  // wave-uniform
         const uint32_t need = ((b0 ? 0u : 1u) | (b1 ? 0u : 2u) | (b2 ? 0u : 4u) | (b3 ? 0u : 8u) | (b4 ? 0u : 16u) |
                                (b5 ? 0u : 32u) | (b6 ? 0u : 64u) | (b7 ? 0u : 128u)) & real;
-        if (STATS) count_dismissed(real & ~need, i, kSuperBlock);
+        if (STATS) count_dismissed(real & ~need, i, 6);
         const int slot = trip & 7;
         pending |= (unsigned long long)need << (slot * 8);
         if (slot == 7 || i + 8 * kSuperBlock >= end) {
