@@ -623,17 +623,18 @@ def main():
             }
         if st.sphere_prefilter_skips:
             # a world too large for the on-chip tables: nearly every ray-sphere pair ends in the packed
-            # single-precision pre-tests (first per block of eight spheres, then per sphere of the blocks that
-            # some lane of the wave cannot dismiss), which the FP64 figures above do not see.  A test costs 17
-            # single-precision flops for a radiance ray (difference 3, two dot products 5 + 5, margin 2, two
-            # products 2) and 7 for a shadow ray (dot product 5, margin 1, square 1).  Counted here: the block
-            # tests only (the per-sphere tests that follow depend on how alike the rays of a wave are).
+            # single-precision pre-tests (per super-block of 64 spheres for every ray, then per block of eight
+            # and per sphere only where a ray cannot dismiss the level above), which the FP64 figures above do
+            # not see.  A test costs 17 single-precision flops for a radiance ray (difference 3, two dot
+            # products 5 + 5, margin 2, two products 2) and 7 for a shadow ray (dot product 5, margin 1,
+            # square 1).  Counted here: the super-block tests only, which every ray runs (how many block and
+            # sphere tests follow depends on the ray).
             groups_now = scene.group_counts()
             n_sph = sum(n for n, g in zip(groups_now, group_table) if g["geo"] == 0)
-            n_blocks = (n_sph + 7) // 8
+            n_blocks = (n_sph + 63) // 64
             f32 = (st.radiance_rays * 17 + st.shadow_rays * 7) * n_blocks
             roofline["bound"] = "valu-issue (packed f32 pre-tests + f64)"
-            roofline["f32_block_test_flops_per_launch"] = f32
+            roofline["f32_super_block_test_flops_per_launch"] = f32
             roofline["pairs_dismissed_by_f32_pre_tests"] = st.sphere_prefilter_skips / max(st.sphere_tests, 1)
             roofline["note"] += (". In this workload the single-precision pre-tests dismiss most ray-sphere pairs "
                                  "before any FP64 operation: `frac` (FP64 flops only) is then no measure of how busy "

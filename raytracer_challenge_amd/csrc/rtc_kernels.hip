@@ -634,7 +634,11 @@ __device__ __forceinline__ Ray32 ray_in_floats(const V3& o, const V3& d, double 
     } else {
         const double oo = fma(o.z, o.z, fma(o.y, o.y, o.x * o.x));
         const float rho = float_up(fmaxf((float)(0x1.6a09e667f3bcdp-20 * oo), 0x1p-100f));
+#ifdef RTC_MUTATE_PREFILTER
+        const float ds = (float)(dd * (1.0 + 0x1p-16));  // test of the tests: the packed test dismisses too eagerly
+#else
         const float ds = (float)(dd * (1.0 - 0x1p-18));
+#endif
         const float dsd = ds > 0x1p-100f ? float_down(ds) : 0.0f;  // 0: nothing is dismissed for this ray
         r.a = {rho, rho};
         r.b = {dsd, dsd};
@@ -780,6 +784,10 @@ __device__ __forceinline__ void sweep_spheres_streamed(const float* __restrict__
 // nothing more (calc.zig:789 only asks whether one exists); the statistics build goes on, to count what the
 // reference intersects.
 constexpr int kSuperBlock = 8 * kSphereBlock;  // spheres per super-block
+#ifndef RTC_VOTE_NUM
+#define RTC_VOTE_NUM 1  // the sphere tests get the trip when (lanes with a sphere waiting) x DEN >= (lanes with a block to do) x NUM
+#define RTC_VOTE_DEN 2  // (measured: 1:4, 1:2, 1:1, 2:1 within 4 % of each other, 1:2 the fastest)
+#endif
 template <bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pairs, const double* __restrict__ bounds,
                                                     const double* __restrict__ inv, const int* __restrict__ order_of,
@@ -855,7 +863,7 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
             if (has_sphere) {  // (for comparison: every lane does its spheres as soon as it has them)
                 while (cands != 0u) {
 #else
-            if (__popcll(with_sphere) >= __popcll(with_eight)) {
+            if (__popcll(with_sphere) * RTC_VOTE_DEN >= __popcll(with_eight) * RTC_VOTE_NUM) {
                 if (has_sphere) {
 #endif
                     const int i = cands_first + (__ffs((int)cands) - 1);
