@@ -619,12 +619,18 @@ __device__ __forceinline__ Pairs4 load_pairs4(const float* __restrict__ p) {
 // rays: a = 2^-25 dist^2 rounded up (the per-ray term of the light-anchored test).
 struct Ray32 {
     float2_t ox, oy, oz, dx, dy, dz, a, b;
+    // For the segment form of the test (pair_clear<.., true>): the end of the stretch of the ray that matters, in
+    // units of the ray-centre product.  Radiance rays: best hit so far times |d|^2, rounded up (+inf: none yet); the
+    // stretch is [0, lim].  Shadow rays: minus the distance to the light, rounded away from zero; the product is
+    // taken from the light, and the stretch is [lim, 0].
+    float lim;
 };
 __device__ __forceinline__ float float_up(float x) { return __uint_as_float(__float_as_uint(x) + 1u); }    // x > 0
 __device__ __forceinline__ float float_down(float x) { return __uint_as_float(__float_as_uint(x) - 1u); }  // x > 0, normal
 template <bool SHADOW>
 __device__ __forceinline__ Ray32 ray_in_floats(const V3& o, const V3& d, double dd, double shadow_margin) {
     Ray32 r;
+    r.lim = 0.0f;  // (set by the sweep that uses the segment form)
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     r.ox = {ox, ox}, r.oy = {oy, oy}, r.oz = {oz, oz}, r.dx = {dx, dx}, r.dy = {dy, dy}, r.dz = {dz, dz};
     if (SHADOW) {
@@ -645,24 +651,59 @@ __device__ __forceinline__ Ray32 ray_in_floats(const V3& o, const V3& d, double 
     }
     return r;
 }
-// two spheres against the ray: c0 / c1 = the pair's first / second sphere is certainly clear of the ray
-template <bool SHADOW>
+// two spheres against the ray: c0 / c1 = the pair's first / second sphere is certainly clear of the ray.
+//
+// SEGMENT = false: clear of the ray's LINE, (|c - o|^2 - bound) |d|^2 > ((c - o).d)^2 with the margins derived at
+// sphere_prefilter_tables (rtc_api.hip): the reference's discriminant is then negative.
+//
+// SEGMENT = true: clear of the stretch of the ray that can matter, t in [0, T] with T the best hit so far (a
+// shadow ray: from its origin to the light).  With q = (c - o).d and tq = q clamped to [0, T |d|^2], the point of
+// that stretch nearest the centre is at t = tq / |d|^2 and its squared distance from the centre is
+// |c - o|^2 - tq (2 q - tq) / |d|^2: the same inequality with tq (2 q - tq) in place of q^2 (they are equal where
+// q lies inside the stretch).  A sphere the stretch clears by the test's margin has both roots behind the origin or
+// both beyond T (one on either side would put the whole stretch inside it), by a relative 2^-22 of the root's
+// scale where the reference's roots are good to 2^-40: the full test would find roots that are neither the hit
+// nor, the origin being outside, an open container; nor can they tie with the hit (a sphere that touches the
+// stretch's end is not clear).  T only ever shrinks during a sweep, so what it lets go stays irrelevant.
+// Roundings: the right side as a function of q has slope 2 tq and tq^2 <= tq (2 q - tq), so the split that covers
+// the error of the computed q (see there) holds as it stands; 2 q - tq lies in [q, 2 q], no cancellation; one more
+// rounded operation than q^2, still inside the factor 1 - 2^-18 ((1 - 2^-22.4)/(1 - 2^-18) > 1 + 2^-19); the limit
+// is rounded outwards; a NaN q gives a NaN right side, which dismisses nothing.  The same holds for a block's sphere:
+// its derivation (sphere_block_bound) uses distances from a set of points to the centres, whichever the set.
+// The statistics build keeps the line form: it counts the pairs the reference finds roots for.
+template <bool SHADOW, bool SEGMENT>
 __device__ __forceinline__ void pair_clear(const float* __restrict__ p, const Ray32& r, bool& c0, bool& c1) {
     const float2_t cx = {p[0], p[1]}, cy = {p[2], p[3]}, cz = {p[4], p[5]}, k = {p[6], p[7]};
+    const float2_t two = {2.0f, 2.0f};
     float2_t lhs, rhs;
     if (SHADOW) {
         const float2_t lcd = __builtin_elementwise_fma(cz, r.dz, __builtin_elementwise_fma(cy, r.dy, cx * r.dx));
         lhs = k - r.a;
-        rhs = lcd * lcd;
+        if (SEGMENT) {
+            const float2_t tq = {__builtin_amdgcn_fmed3f(lcd.x, r.lim, 0.0f), __builtin_amdgcn_fmed3f(lcd.y, r.lim, 0.0f)};
+            rhs = tq * __builtin_elementwise_fma(lcd, two, -tq);
+        } else {
+            rhs = lcd * lcd;
+        }
     } else {
         const float2_t x = cx - r.ox, y = cy - r.oy, z = cz - r.oz;
         const float2_t oc2 = __builtin_elementwise_fma(z, z, __builtin_elementwise_fma(y, y, x * x));
         const float2_t ocd = __builtin_elementwise_fma(z, r.dz, __builtin_elementwise_fma(y, r.dy, x * r.dx));
         lhs = ((oc2 - r.a) - k) * r.b;
-        rhs = ocd * ocd;
+        if (SEGMENT) {
+            const float2_t tq = {__builtin_amdgcn_fmed3f(ocd.x, 0.0f, r.lim), __builtin_amdgcn_fmed3f(ocd.y, 0.0f, r.lim)};
+            rhs = tq * __builtin_elementwise_fma(ocd, two, -tq);
+        } else {
+            rhs = ocd * ocd;
+        }
     }
     c0 = lhs.x > rhs.x;
     c1 = lhs.y > rhs.y;
+}
+// the limit of the segment form from a non-negative double, rounded up (+inf stays +inf)
+__device__ __forceinline__ float segment_limit(double v) {
+    const float f = (float)v;
+    return f < __builtin_huge_valf() ? float_up(f) : __builtin_huge_valf();
 }
 
 template <bool SHADOW, bool STATS>
@@ -707,10 +748,10 @@ __device__ __forceinline__ void sweep_spheres_streamed(const float* __restrict__
     // flags would be kept as bytes in a vector register and cost instructions to pack and unpack)
     auto eight = [&](const float* p, int i) {
         bool c0, c1, c2, c3, c4, c5, c6, c7;
-        pair_clear<SHADOW>(p, r32, c0, c1);
-        pair_clear<SHADOW>(p + 8, r32, c2, c3);
-        pair_clear<SHADOW>(p + 16, r32, c4, c5);
-        pair_clear<SHADOW>(p + 24, r32, c6, c7);
+        pair_clear<SHADOW, false>(p, r32, c0, c1);
+        pair_clear<SHADOW, false>(p + 8, r32, c2, c3);
+        pair_clear<SHADOW, false>(p + 16, r32, c4, c5);
+        pair_clear<SHADOW, false>(p + 24, r32, c6, c7);
         if (STATS || !(c0 && c1 && c2 && c3 && c4 && c5 && c6 && c7)) {
             rest(i, c0);
             rest(i + 1, c1);
@@ -733,10 +774,10 @@ __device__ __forceinline__ void sweep_spheres_streamed(const float* __restrict__
         asm volatile("" ::"s"(G.v[31]) : "memory");
         const Pairs4 N = load_pairs4(g + 32);
         bool b0, b1, b2, b3, b4, b5, b6, b7;
-        pair_clear<SHADOW>(G.v, r32b, b0, b1);
-        pair_clear<SHADOW>(G.v + 8, r32b, b2, b3);
-        pair_clear<SHADOW>(G.v + 16, r32b, b4, b5);
-        pair_clear<SHADOW>(G.v + 24, r32b, b6, b7);
+        pair_clear<SHADOW, false>(G.v, r32b, b0, b1);
+        pair_clear<SHADOW, false>(G.v + 8, r32b, b2, b3);
+        pair_clear<SHADOW, false>(G.v + 16, r32b, b4, b5);
+        pair_clear<SHADOW, false>(G.v + 24, r32b, b6, b7);
         // which blocks this lane cannot dismiss, as a bit mask; the loop below visits the blocks some lane
         // needs (one copy of the per-sphere code, not eight)
         const uint32_t need = (b0 ? 0u : 1u) | (b1 ? 0u : 2u) | (b2 ? 0u : 4u) | (b3 ? 0u : 8u) | (b4 ? 0u : 16u) |
@@ -797,7 +838,15 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                                                     double block_margin_scale, Sweep& s, ContainerSlots& cs,
                                                     SweepCounters& ctr) {
     if (begin >= end) return;
-    const Ray32 r32 = ray_in_floats<SHADOW>(o, d, dd, shadow_margin);
+    Ray32 r32 = ray_in_floats<SHADOW>(o, d, dd, shadow_margin);
+    // the stretch of the ray that matters (pair_clear): up to the best hit so far - on entry the nearest plane's,
+    // brought up to date after every sphere test - or, for a shadow ray, from the light back to the origin; dd
+    // carries the line test's shrink 1 - 2^-27, the factor makes the product an upper bound of T |d|^2
+    auto reach = [&]() -> float {
+        if (SHADOW) return -segment_limit(s.t);
+        return s.idx >= 0 ? segment_limit(s.t * dd * (1.0 + 0x1p-20)) : __builtin_huge_valf();
+    };
+    r32.lim = reach();
     // the same ray for the block and super-block tests: their shrink in the |d|^2 term, their larger per-ray
     // margin for shadow rays (only the two margin terms differ)
     float2_t a_blocks, b_blocks;
@@ -827,10 +876,10 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         r.a = a;
         r.b = b;
         bool c0, c1, c2, c3, c4, c5, c6, c7;
-        pair_clear<SHADOW>(v, r, c0, c1);
-        pair_clear<SHADOW>(v + 8, r, c2, c3);
-        pair_clear<SHADOW>(v + 16, r, c4, c5);
-        pair_clear<SHADOW>(v + 24, r, c6, c7);
+        pair_clear<SHADOW, !STATS>(v, r, c0, c1);
+        pair_clear<SHADOW, !STATS>(v + 8, r, c2, c3);
+        pair_clear<SHADOW, !STATS>(v + 16, r, c4, c5);
+        pair_clear<SHADOW, !STATS>(v + 24, r, c6, c7);
         return (c0 ? 0u : 1u) | (c1 ? 0u : 2u) | (c2 ? 0u : 4u) | (c3 ? 0u : 8u) | (c4 ? 0u : 16u) | (c5 ? 0u : 32u) |
                (c6 ? 0u : 64u) | (c7 ? 0u : 128u);
     };
@@ -880,6 +929,7 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                         for (int k = 0; k < 12; ++k) rec.m[k] = m[k];
                         rec.order = order_of[i];
                         sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                        if (!SHADOW) r32.lim = reach();
                     }
                 }
             }
@@ -912,7 +962,7 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
             }
         }
     };
-    Ray32 r32s = r32;
+    Ray32 r32s = r32;  // (super-blocks are tested before any sphere of the window: the limit is the one on entry, or of the last drain)
     r32s.a = a_blocks;
     r32s.b = b_blocks;
     const float* __restrict__ g = pairs + super_pairs_offset;
@@ -922,10 +972,10 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         asm volatile("" ::"s"(G.v[31]) : "memory");
         const Pairs4 N = load_pairs4(g + 32);
         bool b0, b1, b2, b3, b4, b5, b6, b7;
-        pair_clear<SHADOW>(G.v, r32s, b0, b1);
-        pair_clear<SHADOW>(G.v + 8, r32s, b2, b3);
-        pair_clear<SHADOW>(G.v + 16, r32s, b4, b5);
-        pair_clear<SHADOW>(G.v + 24, r32s, b6, b7);
+        pair_clear<SHADOW, !STATS>(G.v, r32s, b0, b1);
+        pair_clear<SHADOW, !STATS>(G.v + 8, r32s, b2, b3);
+        pair_clear<SHADOW, !STATS>(G.v + 16, r32s, b4, b5);
+        pair_clear<SHADOW, !STATS>(G.v + 24, r32s, b6, b7);
         const uint32_t real = real_bits(i, 6);  // wave-uniform
         const uint32_t need = ((b0 ? 0u : 1u) | (b1 ? 0u : 2u) | (b2 ? 0u : 4u) | (b3 ? 0u : 8u) | (b4 ? 0u : 16u) |
                                (b5 ? 0u : 32u) | (b6 ? 0u : 64u) | (b7 ? 0u : 128u)) & real;
@@ -935,6 +985,7 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         if (slot == 7 || i + 8 * kSuperBlock >= end) {
             drain(i - slot * 8 * kSuperBlock);
             if (SHADOW && !STATS && __ballot(s.idx < 0) == 0ull) break;  // every ray of the wave has its occluder
+            r32s.lim = r32.lim;
         }
         G = N;
     }
