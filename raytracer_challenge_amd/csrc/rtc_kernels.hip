@@ -843,6 +843,10 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
     // brought up to date after every sphere test - or, for a shadow ray, from the light back to the origin; dd
     // carries the line test's shrink 1 - 2^-27, the factor makes the product an upper bound of T |d|^2
     auto reach = [&]() -> float {
+#ifdef RTC_MUTATE_SEGMENT  // test of the tests: a stretch that ends early by more than the tests' own slack
+        if (SHADOW) return -segment_limit(s.t * (1.0 - 0x1p-6));
+        return s.idx >= 0 ? segment_limit(s.t * dd * (1.0 - 0x1p-6)) : __builtin_huge_valf();
+#endif
         if (SHADOW) return -segment_limit(s.t);
         return s.idx >= 0 ? segment_limit(s.t * dd * (1.0 + 0x1p-20)) : __builtin_huge_valf();
     };

@@ -21,7 +21,7 @@ from raytracer_challenge_amd import (Camera, Canvas, Color, Mat4, Material, Patt
                                      byte_color_values, canvas_to_ppm, descs as D, init_glass_sphere, init_point,
                                      init_vector, native, scenes, tiles, view_transform)
 from worlds import (cube_world, grazing_world_and_rays, nested_glass_world, random_world, shadow_grazing_world_and_rays,
-                    tie_world)
+                    tie_world, touching_spheres_world_and_rays)
 
 pytestmark = pytest.mark.gpu
 
@@ -367,6 +367,34 @@ def test_grazing_rays_in_worlds_too_large_for_the_on_chip_tables(seed):
     cpu = O.color_at(w, rays, 2, O.STREAMING)
     with scene_of(w) as sc:
         assert_identical(sc.color_at(rays, 2), cpu, f"shadow grazing, large world, seed {seed}")
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_touching_spheres_in_worlds_too_large_for_the_on_chip_tables(seed):
+    """Large worlds dismiss spheres, blocks and super-blocks that lie behind a ray's origin or beyond its best hit
+    (the stretch form of the packed tests).  Rows of touching, nearly touching and overlapping spheres with rays
+    along the rows: hits that coincide with the next sphere's entry, spheres that end at the origin, occluders
+    that touch a shadow ray's origin from behind.  Colours as the literal integrator's, bit for bit, with and
+    without statistics (the statistics build keeps the line form of the tests) and through the hierarchy; the
+    statistics themselves as the oracle counts them."""
+    w, rays = touching_spheres_world_and_rays(seed)
+    assert len(w.objects) > 32
+    so = D.RtcStats()
+    want = O.color_at(w, rays, 4, O.LITERAL, stats=so)
+    with scene_of(w) as sc:
+        st = D.RtcStats()
+        assert_identical(sc.color_at(rays, 4, st), want, f"touching spheres, seed {seed}, statistics build")
+        assert (st.radiance_rays, st.shadow_rays, st.sphere_hits, st.shaded_hits) == (so.radiance_rays, so.shadow_rays,
+                                                                                     so.sphere_hits, so.shaded_hits)
+        assert_identical(sc.color_at(rays, 4), want, f"touching spheres, seed {seed}")
+        sc.set_integrator(D.RTC_INTEGRATOR_WEIGHTED)
+        got = sc.color_at(rays, 4)
+        fin = np.isfinite(want)
+        scale = max(1.0, float(np.abs(want[fin]).max(initial=0.0)))  # (degenerate rays give huge finite colours)
+        assert np.array_equal(np.isfinite(got), fin) and np.abs(got[fin] - want[fin]).max(initial=0.0) <= TOL * scale
+        sc.set_integrator(D.RTC_INTEGRATOR_POSTORDER)
+        sc.set_acceleration(D.RTC_ACCEL_BVH)
+        assert_identical(sc.color_at(rays, 4), want, "same through the hierarchy")
 
 
 def test_worlds_beyond_the_lds_table_size_and_one_kind_worlds():

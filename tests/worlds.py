@@ -253,3 +253,69 @@ def shadow_grazing_world_and_rays(seed, n_rays=2500):
         rays[k, 3:] = (q - eye) / np.linalg.norm(q - eye)
         k += 1
     return w, rays
+
+
+def touching_spheres_world_and_rays(seed, n_rays=4000):
+    """Rows of spheres that touch, nearly touch or slightly overlap their neighbours (gaps of 0, +-1e-15 ... +-1e-6
+    of the radius), more than 32 of them, with glass, mirrors and diffuse surfaces mixed; the light sits on the
+    axis of the first row.  Rays run along the rows and start outside, inside, exactly on touching points and on
+    surface points facing away from a neighbour, so that the hit of one sphere coincides with (or lies within
+    rounding of) the entry of the next, spheres end exactly at a ray's origin, and shadow rays leave a surface
+    point with an occluder touching it from behind.  Whatever a renderer leaves out because it lies "behind the
+    origin" or "beyond the hit" is decided here in the last bits."""
+    rng = np.random.default_rng(seed)
+    u = lambda lo, hi: float(rng.uniform(lo, hi))
+    w = World()
+    w.light = PointLight(init_point(-9, 0, 0), Color(1, 1, 1))
+    gaps = (0.0, 1e-15, -1e-15, 1e-12, -1e-12, 1e-9, -1e-9, 1e-6, -1e-6, 1e-3, -1e-3)
+    centres = []
+    for row in range(3):
+        r = (1.0, 0.5, 2.0)[row]
+        x = 0.0
+        for k in range(13):
+            gap = gaps[(k + row) % len(gaps)]
+            c = np.array([x, 3.0 * row * (row + 1) / 2.0 * 1.5, 0.25 * row])
+            centres.append((c, r))
+            kind = (k + row) % 3
+            if kind == 0:
+                mat = Material(color=Color(u(0, 0.3), u(0, 0.3), u(0, 0.3)), diffuse=0.4, reflective=0.6, transparency=0.8,
+                               refractive_index=1.0 + 0.1 * (k % 6))
+            elif kind == 1:
+                mat = Material(color=Color(u(0.2, 1), u(0.2, 1), u(0.2, 1)), reflective=u(0.2, 0.8))
+            else:
+                mat = Material(color=Color(u(0.2, 1), u(0.2, 1), u(0.2, 1)), ambient=0.3)
+            m = Mat4.identity().scale(r, r, r)
+            if k % 4 == 3:
+                m = m.rotate_y(0.3 * k)  # the same sphere through a general matrix
+            w.objects.append(Shape("sphere", m.translate(float(c[0]), float(c[1]), float(c[2])), mat))
+            x += 2.0 * r * (1.0 + gap)
+    w.objects.append(Shape("plane", Mat4.identity().translate(0, -3, 0), Material(color=Color(0.5, 0.5, 0.5), reflective=0.2)))
+    rays = np.empty((n_rays, 6))
+    axis = np.array([1.0, 0.0, 0.0])
+    for k in range(n_rays):
+        c, r = centres[int(rng.integers(0, len(centres)))]
+        off = (0.0, 1e-15, -1e-15, 1e-12, 1e-9, -1e-9, 1e-6, 1e-3, 0.3)[int(rng.integers(0, 9))] * r
+        side = np.array([0.0, 1.0, 0.0]) if k % 2 else np.array([0.0, 0.0, 1.0])
+        mode = k % 5
+        sign = 1.0 if (k // 5) % 2 else -1.0
+        if mode == 0:    # from far outside, along the row
+            o = c - sign * axis * (r * u(3, 40)) + side * off
+        elif mode == 1:  # from the touching point with the neighbour
+            o = c + sign * axis * r + side * off
+        elif mode == 2:  # from the centre of a sphere
+            o = c + side * off
+        elif mode == 3:  # from the surface point facing away from where the ray goes (the sphere ends at the origin)
+            o = c - sign * axis * r * (1.0 + off / r) + side * 0.0
+        else:            # from a random surface point in a random direction
+            n = rng.normal(size=3)
+            n /= np.linalg.norm(n)
+            o = c + n * r * (1.0 + off / r)
+        d = sign * axis
+        if mode == 4:
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+        elif k % 3 == 0:
+            d = d + side * u(-1e-3, 1e-3)
+        rays[k, :3] = o
+        rays[k, 3:] = d * (1.0 if k % 2 else 10.0 ** u(-2, 2))
+    return w, rays
