@@ -191,6 +191,8 @@ struct RtcScene {
     size_t sphere_pairs_floats = 0;     // floats per table
     uint32_t block_pairs_offset_radiance = 0, block_pairs_offset_shadow = 0;  // see DevWorld
     uint32_t super_pairs_offset_radiance = 0, super_pairs_offset_shadow = 0;
+    uint32_t group_pairs_offset_radiance = 0, group_pairs_offset_shadow = 0;
+    int32_t sweep_top_log2 = 6;
     double block_shrink = 0.0, block_margin_scale = 1.0;
     double* d_sphere_bounds = nullptr;  // radiance table, then shadow table (see DevWorld)
     size_t sphere_bounds_doubles = 0;   // doubles per table
@@ -269,6 +271,9 @@ rtc::DevWorld dev_world(const RtcScene* s) {
     w.block_pairs_offset_shadow = s->block_pairs_offset_shadow;
     w.super_pairs_offset_radiance = s->super_pairs_offset_radiance;
     w.super_pairs_offset_shadow = s->super_pairs_offset_shadow;
+    w.group_pairs_offset_radiance = s->group_pairs_offset_radiance;
+    w.group_pairs_offset_shadow = s->group_pairs_offset_shadow;
+    w.sweep_top_log2 = s->sweep_top_log2;
     w.block_shrink = s->block_shrink;
     w.block_margin_scale = s->block_margin_scale;
     w.sphere_bounds_radiance = s->d_sphere_bounds;
@@ -1180,15 +1185,17 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 return std::isfinite(t[3]) && std::isfinite(t[7]) && std::isfinite(t[11]);
             };
             // Spatial order by recursive median split: the range is cut across the axis along which its centres
-            // spread most, at a table position that is a multiple of the block size (of eight blocks while the range
-            // is longer than that), so that every block - and every run of eight blocks - is one cell of the split:
+            // spread most, at a table position that is a multiple of the block size (of eight blocks, of sixty-four
+            // blocks while the range is longer than that), so that every block - and every aligned run of eight or
+            // sixty-four blocks - is one cell of the split:
             // compact clusters, whose bounding spheres few rays cross.  (Shapes without a finite centre go last.)
             auto centre = [&](uint64_t i, int a) -> double { return shapes[i].transform[3 + 4 * a]; };
             size_t table_pos = 0;  // where the group starts in the table: blocks are counted from position 0
             std::function<void(std::vector<uint64_t>&, size_t, size_t)> split = [&](std::vector<uint64_t>& v, size_t lo_i, size_t hi_i) {
                 const size_t n_here = hi_i - lo_i;
                 if (n_here <= (size_t)rtc::kSphereBlock) return;
-                const size_t unit = n_here > 8u * rtc::kSphereBlock ? 8u * rtc::kSphereBlock : (size_t)rtc::kSphereBlock;
+                const size_t unit = n_here > 64u * rtc::kSphereBlock ? 64u * rtc::kSphereBlock
+                                    : (n_here > 8u * rtc::kSphereBlock ? 8u * rtc::kSphereBlock : (size_t)rtc::kSphereBlock);
                 // absolute table position of the cut: the multiple of `unit` nearest the middle, inside the range
                 const size_t abs_lo = table_pos + lo_i, abs_hi = table_pos + hi_i;
                 size_t cut = ((abs_lo + abs_hi) / 2 + unit / 2) / unit * unit;
@@ -1351,7 +1358,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         }
         // the block tests' tables behind them: per block of kSphereBlock consecutive spheres a bounding sphere of
         // the members' bounding spheres, two blocks per record of 8 floats, padded like the tables above; and behind
-        // those the same per super-block (eight blocks = 64 consecutive spheres)
+        // those the same per super-block (eight blocks = 64 consecutive spheres) and per group (eight super-blocks)
         {
             std::vector<const RtcScene::SphereBound*> by_pos(n_sph, nullptr);
             for (const RtcScene::SphereBound& sb : sc->sphere_bounds) by_pos[(size_t)sb.pos] = &sb;
@@ -1365,7 +1372,8 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 }
                 return v;
             };
-            const std::vector<BlockBound> blocks = bounds_of(rtc::kSphereBlock), supers = bounds_of(8 * rtc::kSphereBlock);
+            const std::vector<BlockBound> blocks = bounds_of(rtc::kSphereBlock), supers = bounds_of(8 * rtc::kSphereBlock),
+                                          groups = bounds_of(64 * rtc::kSphereBlock);
             // one shrink for the whole scene (a larger one only makes a test more cautious); beyond 2^-12 the
             // blocks of this scene are too loose to be worth a test
             const bool usable = eps_blocks > 0 && eps_blocks <= 0x1p-12;
@@ -1402,6 +1410,9 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
             };
             append_level(blocks, &sc->block_pairs_offset_radiance, &sc->block_pairs_offset_shadow);
             append_level(supers, &sc->super_pairs_offset_radiance, &sc->super_pairs_offset_shadow);
+            append_level(groups, &sc->group_pairs_offset_radiance, &sc->group_pairs_offset_shadow);
+            // which level the sweep tests wave-wide: groups once there are enough of them to save trips
+            sc->sweep_top_log2 = n_sph > 2048 ? 9 : 6;
         }
         SCENE_TRY(hipMalloc((void**)&sc->d_sphere_pairs, pairs.size() * sizeof(float)));
         SCENE_TRY(hipMemcpy(sc->d_sphere_pairs, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));

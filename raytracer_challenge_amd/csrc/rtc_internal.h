@@ -137,6 +137,10 @@ struct DevWorld {
     // and behind those, in the same format, one entry per SUPER-BLOCK: eight blocks that follow each other in the
     // table (64 spheres; the table order is a spatial one, so they are a cluster too), with the same shrink
     uint32_t super_pairs_offset_radiance, super_pairs_offset_shadow;
+    // and one entry per GROUP of eight super-blocks (512 spheres); sweep_top_log2 says which level the sweep tests
+    // wave-wide: 6 = super-blocks, 9 = groups (worlds of more than 2048 spheres)
+    uint32_t group_pairs_offset_radiance, group_pairs_offset_shadow;
+    int32_t sweep_top_log2, sweep_pad;
     double block_shrink, block_margin_scale;
     int32_t n;
     int32_t group[kSweepGroups + 1];

@@ -834,9 +834,9 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                                                     const double* __restrict__ inv, const int* __restrict__ order_of,
                                                     int begin, int end, const V3& o, const V3& d, double dd,
                                                     double shadow_margin, uint32_t block_pairs_offset,
-                                                    uint32_t super_pairs_offset, double block_shrink,
-                                                    double block_margin_scale, Sweep& s, ContainerSlots& cs,
-                                                    SweepCounters& ctr) {
+                                                    uint32_t super_pairs_offset, uint32_t group_pairs_offset, int top_log2,
+                                                    double block_shrink, double block_margin_scale, Sweep& s,
+                                                    ContainerSlots& cs, SweepCounters& ctr) {
     if (begin >= end) return;
     Ray32 r32 = ray_in_floats<SHADOW>(o, d, dd, shadow_margin);
     // the stretch of the ray that matters (pair_clear): up to the best hit so far - on entry the nearest plane's,
@@ -861,10 +861,16 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         if (SHADOW && !(block_shrink > 0.0)) a_blocks = {__builtin_huge_valf(), __builtin_huge_valf()};  // dismisses nothing
     }
     static_assert(kSphereBlock == 8 && kSuperBlock == 64, "eight member bits per block, eight block bits per super-block; shifts by 3 and 6");
-    const float* __restrict__ block_table = pairs + block_pairs_offset;
-    unsigned long long pending = 0ull;  // per lane: super-blocks of the current window this ray cannot dismiss
-    uint32_t blocks = 0u;               // per lane: blocks of the super-block in hand this ray cannot dismiss ...
-    int blocks_first = 0;               // ... and the table position of that super-block's first sphere
+    // The level that is tested wave-wide (wave-uniform, chosen at upload): super-blocks (top_log2 == 6), or in worlds
+    // of thousands of spheres GROUPS of eight super-blocks (512 spheres, top_log2 == 9; a fourth table of the same
+    // kind), whose super-blocks are then one more kind of item of the lanes' work loop.
+    const bool top_is_group = top_log2 == 9;
+    const int top_level = top_is_group ? 2 : 1;  // what an entry of `pending` is, as a level of the work loop
+    unsigned long long pending = 0ull;  // per lane: top-level entries of the current window this ray cannot dismiss
+    uint32_t sub = 0u;                  // per lane: bits 8-15 the super-blocks of the group in hand this ray cannot dismiss,
+                                        // bits 0-7 the blocks of the super-block in hand ...
+    int supers_first = 0;               // ... the table position of that group's first sphere ...
+    int blocks_first = 0;               // ... and of that super-block's first sphere
     uint32_t cands = 0u;                // per lane: spheres of the block in hand the packed test could not dismiss ...
     int cands_first = 0;                // ... and the table position of that block's first sphere
     // eight entries (four records of two) at `src` against the ray with margins a, b: bit k set = entry k not dismissed
@@ -907,9 +913,9 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
     // lane does: a lane with spheres waiting takes no further block until they are done.
     auto drain = [&](int window_first) {
         for (;;) {
-            if (SHADOW && !STATS && s.idx >= 0) pending = 0ull, blocks = 0u, cands = 0u;
+            if (SHADOW && !STATS && s.idx >= 0) pending = 0ull, sub = 0u, cands = 0u;
             const bool has_sphere = cands != 0u;
-            const bool has_eight = !has_sphere && (pending | blocks) != 0ull;
+            const bool has_eight = !has_sphere && (pending | sub) != 0ull;
             const unsigned long long with_sphere = __ballot(has_sphere), with_eight = __ballot(has_eight);
             if ((with_sphere | with_eight) == 0ull) break;
 #ifdef RTC_NO_SPHERE_VOTE
@@ -942,37 +948,44 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
 #else
             else if (has_eight) {
 #endif
-                const bool is_block = blocks != 0u;
-                int first;  // table position of the first sphere of the item
-                if (is_block) {
-                    first = blocks_first + (__ffs((int)blocks) - 1) * kSphereBlock;
-                    blocks &= blocks - 1u;
+                // The deepest kind of item the lane holds: a block (level 0: its entries are spheres), a super-block
+                // (level 1: blocks) or a group (level 2: super-blocks).  `sub` keeps the blocks in hand in bits 0-7 and
+                // the super-blocks in hand in bits 8-15, so its lowest set bit is the deepest item.  Everything below
+                // is selects and shifts on that: one copy of the loads and tests serves all levels.
+                int level, first;  // `first`: table position of the first sphere of the item
+                if (sub != 0u) {
+                    const int bit = __ffs((int)sub) - 1;
+                    sub &= sub - 1u;
+                    level = bit >> 3;
+                    first = (level ? supers_first : blocks_first) + ((bit & 7) << (3 + 3 * level));
                 } else {
-                    first = window_first + (__ffsll((long long)pending) - 1) * kSuperBlock;
+                    level = top_level;
+                    first = window_first + ((__ffsll((long long)pending) - 1) << top_log2);
                     pending &= pending - 1ull;
                 }
-                // a block's spheres: 4 floats each from `pairs`; a super-block's blocks: 4 floats each from the block table
-                const float* __restrict__ src = is_block ? pairs + (size_t)(uint32_t)first * 4 : block_table + (size_t)((uint32_t)first >> 3) * 4;
-                const uint32_t real = real_bits(first, is_block ? 0 : 3);
-                const uint32_t open = eight(src, is_block ? r32.a : a_blocks, is_block ? r32.b : b_blocks) & real;
-                if (STATS) count_dismissed(real & ~open, first, is_block ? 0 : 3);
-                if (is_block) {
-                    cands = open;
-                    cands_first = first;
-                } else {
-                    blocks = open;
-                    blocks_first = first;
-                }
+                // the item's eight entries: 4 floats each, from the table of the level below (all tables are parts of `pairs`)
+                const int unit_log2 = 3 * level;
+                const uint32_t table = level == 0 ? 0u : (level == 1 ? block_pairs_offset : super_pairs_offset);
+                const float* __restrict__ src = pairs + ((size_t)table + (size_t)((uint32_t)first >> unit_log2) * 4);
+                const uint32_t real = real_bits(first, unit_log2);
+                const uint32_t open = eight(src, level == 0 ? r32.a : a_blocks, level == 0 ? r32.b : b_blocks) & real;
+                if (STATS) count_dismissed(real & ~open, first, unit_log2);
+                cands = level == 0 ? open : 0u;
+                cands_first = level == 0 ? first : cands_first;
+                sub |= level == 0 ? 0u : open << (8 * (level - 1));
+                blocks_first = level == 1 ? first : blocks_first;
+                supers_first = level == 2 ? first : supers_first;
             }
         }
     };
     Ray32 r32s = r32;  // (super-blocks are tested before any sphere of the window: the limit is the one on entry, or of the last drain)
     r32s.a = a_blocks;
     r32s.b = b_blocks;
-    const float* __restrict__ g = pairs + super_pairs_offset;
+    const float* __restrict__ g = pairs + (top_is_group ? group_pairs_offset : super_pairs_offset);
     Pairs4 G = load_pairs4(g);
     int trip = 0;
-    for (int i = begin; i < end; i += 8 * kSuperBlock, g += 32, ++trip) {
+    const int per_trip = 8 << top_log2;  // spheres covered by the eight top-level entries of a trip
+    for (int i = begin; i < end; i += per_trip, g += 32, ++trip) {
         asm volatile("" ::"s"(G.v[31]) : "memory");
         const Pairs4 N = load_pairs4(g + 32);
         bool b0, b1, b2, b3, b4, b5, b6, b7;
@@ -980,14 +993,14 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         pair_clear<SHADOW, !STATS>(G.v + 8, r32s, b2, b3);
         pair_clear<SHADOW, !STATS>(G.v + 16, r32s, b4, b5);
         pair_clear<SHADOW, !STATS>(G.v + 24, r32s, b6, b7);
-        const uint32_t real = real_bits(i, 6);  // wave-uniform
+        const uint32_t real = real_bits(i, top_log2);  // wave-uniform
         const uint32_t need = ((b0 ? 0u : 1u) | (b1 ? 0u : 2u) | (b2 ? 0u : 4u) | (b3 ? 0u : 8u) | (b4 ? 0u : 16u) |
                                (b5 ? 0u : 32u) | (b6 ? 0u : 64u) | (b7 ? 0u : 128u)) & real;
-        if (STATS) count_dismissed(real & ~need, i, 6);
+        if (STATS) count_dismissed(real & ~need, i, top_log2);
         const int slot = trip & 7;
         pending |= (unsigned long long)need << (slot * 8);
-        if (slot == 7 || i + 8 * kSuperBlock >= end) {
-            drain(i - slot * 8 * kSuperBlock);
+        if (slot == 7 || i + per_trip >= end) {
+            drain(i - slot * per_trip);
             if (SHADOW && !STATS && __ballot(s.idx < 0) == 0ull) break;  // every ray of the wave has its occluder
             r32s.lim = r32.lim;
         }
@@ -1105,8 +1118,9 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
 #ifndef RTC_NO_LANE_LISTS
         sweep_spheres_lanes<SHADOW, STATS>(sphere_pairs, sphere_bounds, w.inv, order_of, w.group[0], w.group[2], o, d, dd, shadow_margin,
                                            SHADOW ? w.block_pairs_offset_shadow : w.block_pairs_offset_radiance,
-                                           SHADOW ? w.super_pairs_offset_shadow : w.super_pairs_offset_radiance, w.block_shrink,
-                                           w.block_margin_scale, s, cs, ctr);
+                                           SHADOW ? w.super_pairs_offset_shadow : w.super_pairs_offset_radiance,
+                                           SHADOW ? w.group_pairs_offset_shadow : w.group_pairs_offset_radiance, w.sweep_top_log2,
+                                           w.block_shrink, w.block_margin_scale, s, cs, ctr);
 #else
         sweep_spheres_streamed<SHADOW, STATS>(sphere_pairs, sphere_bounds, tab, order_of, w.group[0], w.group[1], w.group[2], o, d, dd,
                                               shadow_margin, SHADOW ? w.block_pairs_offset_shadow : w.block_pairs_offset_radiance,
