@@ -193,6 +193,7 @@ struct RtcScene {
     uint32_t super_pairs_offset_radiance = 0, super_pairs_offset_shadow = 0;
     uint32_t group_pairs_offset_radiance = 0, group_pairs_offset_shadow = 0;
     int32_t sweep_top_log2 = 6;
+    uint32_t sweep_axis_mask[3] = {0, 0, 0};  // see DevWorld
     double block_shrink = 0.0, block_margin_scale = 1.0;
     double* d_sphere_bounds = nullptr;  // radiance table, then shadow table (see DevWorld)
     size_t sphere_bounds_doubles = 0;   // doubles per table
@@ -274,6 +275,7 @@ rtc::DevWorld dev_world(const RtcScene* s) {
     w.group_pairs_offset_radiance = s->group_pairs_offset_radiance;
     w.group_pairs_offset_shadow = s->group_pairs_offset_shadow;
     w.sweep_top_log2 = s->sweep_top_log2;
+    for (int a = 0; a < 3; ++a) w.sweep_axis_mask[a] = s->sweep_axis_mask[a];
     w.block_shrink = s->block_shrink;
     w.block_margin_scale = s->block_margin_scale;
     w.sphere_bounds_radiance = s->d_sphere_bounds;
@@ -1170,6 +1172,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
     std::vector<int32_t> order(n_shapes ? n_shapes : 1, 0);
     std::vector<rtc::DevShade> shade_tab(n_shapes);
     int32_t group[rtc::kSweepGroups + 1] = {};
+    uint32_t axis_mask[3] = {0, 0, 0};  // see DevWorld::sweep_axis_mask
     {
         size_t pos = 0;
         // Members of every group in list order; in a world too large for the on-chip tables the spheres of a
@@ -1184,34 +1187,54 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
                 const double* t = shapes[i].transform;
                 return std::isfinite(t[3]) && std::isfinite(t[7]) && std::isfinite(t[11]);
             };
-            // Spatial order by recursive median split: the range is cut across the axis along which its centres
-            // spread most, at a table position that is a multiple of the block size (of eight blocks, of sixty-four
-            // blocks while the range is longer than that), so that every block - and every aligned run of eight or
-            // sixty-four blocks - is one cell of the split:
-            // compact clusters, whose bounding spheres few rays cross.  (Shapes without a finite centre go last.)
+            // Spatial order in which the BITS of a table position mean something: a range is cut at the table
+            // position inside it that is a multiple of the highest power of two, 2^b, and the spheres with the
+            // smaller coordinate along axis(b) go below the cut.  Inside every aligned run of 2^(b+1) positions
+            // bit b then says on which side of a plane across axis(b) a sphere lies - the same axis for every run
+            // - so every aligned block of 8, 64, 512 ... positions is a cell of the subdivision (compact clusters,
+            // whose bounding spheres few rays cross), and a ray that visits the entries of such a run in the order
+            // of `position XOR mask`, mask bit b set where its direction along axis(b) is negative, visits them front
+            // to back (sweep_spheres_lanes; sweep_axis_mask).  axis(b) follows the extents of the scene: from the
+            // highest bit down, the axis along which a cell of that level is longest, the cell then halved.
+            // (Shapes without a finite centre go last.)
             auto centre = [&](uint64_t i, int a) -> double { return shapes[i].transform[3 + 4 * a]; };
-            size_t table_pos = 0;  // where the group starts in the table: blocks are counted from position 0
-            std::function<void(std::vector<uint64_t>&, size_t, size_t)> split = [&](std::vector<uint64_t>& v, size_t lo_i, size_t hi_i) {
-                const size_t n_here = hi_i - lo_i;
-                if (n_here <= (size_t)rtc::kSphereBlock) return;
-                const size_t unit = n_here > 64u * rtc::kSphereBlock ? 64u * rtc::kSphereBlock
-                                    : (n_here > 8u * rtc::kSphereBlock ? 8u * rtc::kSphereBlock : (size_t)rtc::kSphereBlock);
-                // absolute table position of the cut: the multiple of `unit` nearest the middle, inside the range
-                const size_t abs_lo = table_pos + lo_i, abs_hi = table_pos + hi_i;
-                size_t cut = ((abs_lo + abs_hi) / 2 + unit / 2) / unit * unit;
-                if (cut <= abs_lo) cut += unit;
-                if (cut >= abs_hi) cut -= unit;
-                if (cut <= abs_lo || cut >= abs_hi) return;  // the range lies inside one unit
-                double lo_c[3], hi_c[3];
-                for (int a = 0; a < 3; ++a) lo_c[a] = hi_c[a] = centre(v[lo_i], a);
-                for (size_t k = lo_i; k < hi_i; ++k)
+            int axis_of_bit[32];
+            {
+                double lo_c[3] = {0, 0, 0}, hi_c[3] = {0, 0, 0};
+                bool any = false;
+                for (uint64_t i = 0; i < n_shapes; ++i) {
+                    if (shapes[i].geo != RTC_GEO_SPHERE || !centre_ok(i)) continue;
                     for (int a = 0; a < 3; ++a) {
-                        lo_c[a] = std::fmin(lo_c[a], centre(v[k], a));
-                        hi_c[a] = std::fmax(hi_c[a], centre(v[k], a));
+                        lo_c[a] = any ? std::fmin(lo_c[a], centre(i, a)) : centre(i, a);
+                        hi_c[a] = any ? std::fmax(hi_c[a], centre(i, a)) : centre(i, a);
                     }
-                int axis = 0;
-                for (int a = 1; a < 3; ++a)
-                    if (hi_c[a] - lo_c[a] > hi_c[axis] - lo_c[axis]) axis = a;
+                    any = true;
+                }
+                double ext[3] = {hi_c[0] - lo_c[0], hi_c[1] - lo_c[1], hi_c[2] - lo_c[2]};
+                int top = 0;
+                while ((1ull << (top + 1)) < n_shapes) ++top;
+                for (int bit = 31; bit >= 0; --bit) {
+                    int axis = 0;
+                    for (int a = 1; a < 3; ++a)
+                        if (ext[a] > ext[axis]) axis = a;
+                    axis_of_bit[bit] = axis;
+                    if (bit <= top) ext[axis] *= 0.5;
+                }
+                for (int bit = 3; bit < 32; ++bit) axis_mask[axis_of_bit[bit]] |= 1u << bit;
+            }
+            size_t table_pos = 0;  // where the group starts in the table: positions are counted from 0
+            std::function<void(std::vector<uint64_t>&, size_t, size_t)> split = [&](std::vector<uint64_t>& v, size_t lo_i, size_t hi_i) {
+                const size_t abs_lo = table_pos + lo_i, abs_hi = table_pos + hi_i;
+                if (abs_hi - abs_lo < 2) return;
+                // the multiple of the highest power of two strictly inside (abs_lo, abs_hi)
+                int bit = 31;
+                size_t cut = 0;
+                for (; bit >= 3; --bit) {
+                    cut = ((abs_lo >> bit) + 1) << bit;
+                    if (cut < abs_hi) break;
+                }
+                if (bit < 3) return;  // the range lies inside one block
+                const int axis = axis_of_bit[bit];
                 const size_t mid = cut - table_pos;
                 std::nth_element(v.begin() + lo_i, v.begin() + mid, v.begin() + hi_i, [&](uint64_t x, uint64_t y) {
                     const double cx = centre(x, axis), cy = centre(y, axis);
@@ -1413,6 +1436,7 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
             append_level(groups, &sc->group_pairs_offset_radiance, &sc->group_pairs_offset_shadow);
             // which level the sweep tests wave-wide: groups once there are enough of them to save trips
             sc->sweep_top_log2 = n_sph > 2048 ? 9 : 6;
+            for (int a = 0; a < 3; ++a) sc->sweep_axis_mask[a] = axis_mask[a];
         }
         SCENE_TRY(hipMalloc((void**)&sc->d_sphere_pairs, pairs.size() * sizeof(float)));
         SCENE_TRY(hipMemcpy(sc->d_sphere_pairs, pairs.data(), pairs.size() * sizeof(float), hipMemcpyHostToDevice));

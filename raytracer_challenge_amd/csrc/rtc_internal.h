@@ -141,6 +141,10 @@ struct DevWorld {
     // wave-wide: 6 = super-blocks, 9 = groups (worlds of more than 2048 spheres)
     uint32_t group_pairs_offset_radiance, group_pairs_offset_shadow;
     int32_t sweep_top_log2, sweep_pad;
+    // The spheres' table order is a spatial one in which bit b of a table position (b >= 3) says on which side of a
+    // plane across axis(b) the sphere lies within its aligned run of 2^(b+1) positions (rtc_scene_create):
+    // sweep_axis_mask[a] has the bits b with axis(b) == a, and sweep_pad2 keeps the struct's size a multiple of 8
+    uint32_t sweep_axis_mask[3], sweep_pad2;
     double block_shrink, block_margin_scale;
     int32_t n;
     int32_t group[kSweepGroups + 1];

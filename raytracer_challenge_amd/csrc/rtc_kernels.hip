@@ -41,6 +41,9 @@ constexpr int kBlock = 256;
 #ifndef RTC_WAVES_PER_EU
 #define RTC_WAVES_PER_EU 4  // minimum waves per SIMD the register allocation must allow (<= 128 VGPRs)
 #endif
+#ifndef RTC_WAVES_PER_EU_LARGE
+#define RTC_WAVES_PER_EU_LARGE 4  // the same for the kernels of worlds beyond the on-chip tables (TABLES == 0)
+#endif
 
 struct V3 {
     double x, y, z;
@@ -825,6 +828,31 @@ __device__ __forceinline__ void sweep_spheres_streamed(const float* __restrict__
 // nothing more (calc.zig:789 only asks whether one exists); the statistics build goes on, to count what the
 // reference intersects.
 constexpr int kSuperBlock = 8 * kSphereBlock;  // spheres per super-block
+// Bit k of x moved to bit k XOR m (m < 8, x an 8-bit mask; m < 64, x a 64-bit mask): conditional swaps of neighbouring
+// bits, pairs, nibbles ...  The spheres' table order makes `position XOR (where the ray's direction is negative)` a
+// front-to-back order (rtc_scene_create), so the lowest set bit of the result is the nearest entry left.
+__device__ __forceinline__ uint32_t in_visiting_order8(uint32_t x, uint32_t m) {
+    uint32_t t = ((x & 0x55u) << 1) | ((x >> 1) & 0x55u);
+    x = (m & 1u) ? t : x;
+    t = ((x & 0x33u) << 2) | ((x >> 2) & 0x33u);
+    x = (m & 2u) ? t : x;
+    t = ((x & 0x0fu) << 4) | ((x >> 4) & 0x0fu);
+    return (m & 4u) ? t : x;
+}
+__device__ __forceinline__ unsigned long long in_visiting_order64(unsigned long long x, uint32_t m) {
+    unsigned long long t = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+    x = (m & 1u) ? t : x;
+    t = ((x & 0x3333333333333333ull) << 2) | ((x >> 2) & 0x3333333333333333ull);
+    x = (m & 2u) ? t : x;
+    t = ((x & 0x0f0f0f0f0f0f0f0full) << 4) | ((x >> 4) & 0x0f0f0f0f0f0f0f0full);
+    x = (m & 4u) ? t : x;
+    t = ((x & 0x00ff00ff00ff00ffull) << 8) | ((x >> 8) & 0x00ff00ff00ff00ffull);
+    x = (m & 8u) ? t : x;
+    t = ((x & 0x0000ffff0000ffffull) << 16) | ((x >> 16) & 0x0000ffff0000ffffull);
+    x = (m & 16u) ? t : x;
+    t = (x << 32) | (x >> 32);
+    return (m & 32u) ? t : x;
+}
 #ifndef RTC_VOTE_NUM
 #define RTC_VOTE_NUM 1  // the sphere tests get the trip when (lanes with a sphere waiting) x DEN >= (lanes with a block to do) x NUM
 #define RTC_VOTE_DEN 2  // (measured: 1:4, 1:2, 1:1, 2:1 within 4 % of each other, 1:2 the fastest)
@@ -835,7 +863,7 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                                                     int begin, int end, const V3& o, const V3& d, double dd,
                                                     double shadow_margin, uint32_t block_pairs_offset,
                                                     uint32_t super_pairs_offset, uint32_t group_pairs_offset, int top_log2,
-                                                    double block_shrink, double block_margin_scale, Sweep& s,
+                                                    uint32_t order_mask, double block_shrink, double block_margin_scale, Sweep& s,
                                                     ContainerSlots& cs, SweepCounters& ctr) {
     if (begin >= end) return;
     Ray32 r32 = ray_in_floats<SHADOW>(o, d, dd, shadow_margin);
@@ -963,10 +991,13 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                     const int bit = __ffs((int)sub) - 1;
                     sub &= sub - 1u;
                     level = bit >> 3;
-                    first = (level ? supers_first : blocks_first) + ((bit & 7) << (3 + 3 * level));
+                    // (the masks are kept in visiting order: entry = place XOR the ray's order mask at that level)
+                    const int entry = (bit & 7) ^ (int)((order_mask >> (3 + 3 * level)) & 7u);
+                    first = (level ? supers_first : blocks_first) + (entry << (3 + 3 * level));
                 } else {
                     level = top_level;
-                    first = window_first + ((__ffsll((long long)pending) - 1) << top_log2);
+                    const int entry = (__ffsll((long long)pending) - 1) ^ (int)((order_mask >> top_log2) & 63u);
+                    first = window_first + (entry << top_log2);
                     pending &= pending - 1ull;
                 }
                 // the item's eight entries: 4 floats each, from the table of the level below (all tables are parts of `pairs`)
@@ -978,7 +1009,7 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                 if (STATS) count_dismissed(real & ~open, first, unit_log2);
                 cands = level == 0 ? open : 0u;
                 cands_first = level == 0 ? first : cands_first;
-                sub |= level == 0 ? 0u : open << (8 * (level - 1));
+                sub |= level == 0 ? 0u : in_visiting_order8(open, (order_mask >> (3 * level)) & 7u) << (8 * (level - 1));
                 blocks_first = level == 1 ? first : blocks_first;
                 supers_first = level == 2 ? first : supers_first;
             }
@@ -1006,6 +1037,7 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         const int slot = trip & 7;
         pending |= (unsigned long long)need << (slot * 8);
         if (slot == 7 || i + per_trip >= end) {
+            if (!SHADOW) pending = in_visiting_order64(pending, (order_mask >> top_log2) & 63u);
             drain(i - slot * per_trip);
             if (SHADOW && !STATS && __ballot(s.idx < 0) == 0ull) break;  // every ray of the wave has its occluder
             r32s.lim = r32.lim;
@@ -1126,6 +1158,9 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
                                            SHADOW ? w.block_pairs_offset_shadow : w.block_pairs_offset_radiance,
                                            SHADOW ? w.super_pairs_offset_shadow : w.super_pairs_offset_radiance,
                                            SHADOW ? w.group_pairs_offset_shadow : w.group_pairs_offset_radiance, w.sweep_top_log2,
+                                           SHADOW ? 0u
+                                                  : (d.x < 0 ? w.sweep_axis_mask[0] : 0u) | (d.y < 0 ? w.sweep_axis_mask[1] : 0u) |
+                                                        (d.z < 0 ? w.sweep_axis_mask[2] : 0u),
                                            w.block_shrink, w.block_margin_scale, s, cs, ctr);
 #else
         sweep_spheres_streamed<SHADOW, STATS>(sphere_pairs, sphere_bounds, tab, order_of, w.group[0], w.group[1], w.group[2], o, d, dd,
@@ -1263,7 +1298,7 @@ __device__ __forceinline__ WorldArg world_argument() {
 // TABLES: 0 = per-hit tables gathered from global memory, 1 = from their LDS copy (small
 // worlds), 2 = global memory and the spheres swept through the hierarchy.
 template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
-__global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const double* __restrict__ g_tab,
+__global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_WAVES_PER_EU) void render_kernel(const double* __restrict__ g_tab,
                                                         const DevShade* __restrict__ g_shade,
                                                         const int* __restrict__ g_order,
                                                         const double* __restrict__ g_rays,
@@ -1661,7 +1696,7 @@ __global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_kernel(const 
 // A non-finite Schlick reflectance does not poison a childless hit's colour as calc.zig:466 would
 // (weights only reach children).
 template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
-__global__ __launch_bounds__(kBlock, RTC_WAVES_PER_EU) void render_weighted_kernel(
+__global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_WAVES_PER_EU) void render_weighted_kernel(
     const double* __restrict__ g_tab, const DevShade* __restrict__ g_shade, const int* __restrict__ g_order,
     const double* __restrict__ g_rays, const uint32_t* __restrict__ g_tile_order, double* __restrict__ g_out,
     uint32_t* __restrict__ g_counter, unsigned long long* __restrict__ g_stats, const double* __restrict__ g_bounds_r,
