@@ -623,18 +623,20 @@ def main():
             }
         if st.sphere_prefilter_skips:
             # a world too large for the on-chip tables: nearly every ray-sphere pair ends in the packed
-            # single-precision pre-tests (per super-block of 64 spheres for every ray, then per block of eight
-            # and per sphere only where a ray cannot dismiss the level above), which the FP64 figures above do
-            # not see.  A test costs 17 single-precision flops for a radiance ray (difference 3, two dot
-            # products 5 + 5, margin 2, two products 2) and 7 for a shadow ray (dot product 5, margin 1,
-            # square 1).  Counted here: the super-block tests only, which every ray runs (how many block and
-            # sphere tests follow depends on the ray).
+            # single-precision pre-tests (per group of 512 spheres - per super-block of 64 in worlds of at most
+            # 2048 spheres - for every ray, then per super-block, block of eight and sphere only where a ray
+            # cannot dismiss the level above), which the FP64 figures above do not see.  A test costs 20
+            # single-precision flops for a radiance ray (difference 3, two dot products 5 + 5, margin 2, the
+            # clamped product 4, one product 1) and 10 for a shadow ray (dot product 5, margin 1, clamped
+            # product 4).  Counted here: the top-level tests only, which every ray runs (how many tests follow
+            # depends on the ray).
             groups_now = scene.group_counts()
             n_sph = sum(n for n, g in zip(groups_now, group_table) if g["geo"] == 0)
-            n_blocks = (n_sph + 63) // 64
-            f32 = (st.radiance_rays * 17 + st.shadow_rays * 7) * n_blocks
+            top = 512 if n_sph > 2048 else 64
+            n_blocks = (n_sph + top - 1) // top
+            f32 = (st.radiance_rays * 20 + st.shadow_rays * 10) * n_blocks
             roofline["bound"] = "valu-issue (packed f32 pre-tests + f64)"
-            roofline["f32_super_block_test_flops_per_launch"] = f32
+            roofline["f32_top_level_test_flops_per_launch"] = f32
             roofline["pairs_dismissed_by_f32_pre_tests"] = st.sphere_prefilter_skips / max(st.sphere_tests, 1)
             roofline["note"] += (". In this workload the single-precision pre-tests dismiss most ray-sphere pairs "
                                  "before any FP64 operation: `frac` (FP64 flops only) is then no measure of how busy "
