@@ -1129,7 +1129,7 @@ __device__ __forceinline__ void sweep_spheres_bvh(const double* __restrict__ tab
 
 // SHADOW: s.t holds the distance to the light on entry and only roots in [0, s.t) are
 // accepted (calc.zig:789: hit.t < distance); containers are not tracked.
-template <bool SHADOW, bool STATS, bool ACCEL, bool STREAM>
+template <bool SHADOW, bool STATS, bool ACCEL, bool STREAM, bool SLIM = false>
 __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, const int* __restrict__ order_of,
                                             const double* __restrict__ sphere_bounds,
                                             const float* __restrict__ sphere_pairs, const DevWorld& w, const V3& o,
@@ -1149,7 +1149,8 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
     }
     sweep_group<kPlaneAxis, SHADOW, STATS>(tab, order_of, w.group[2], w.group[3], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     sweep_group<kPlaneGeneral, SHADOW, STATS>(tab, order_of, w.group[3], w.group[4], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
-    sweep_group<kCube, SHADOW, STATS>(tab, order_of, w.group[4], w.group[5], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
+    // (SLIM: a world without cubes and without spheres whose inverse has off-diagonal entries; their loops are left out)
+    if (!SLIM) sweep_group<kCube, SHADOW, STATS>(tab, order_of, w.group[4], w.group[5], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     if (ACCEL) {
         if (!(SHADOW && s.idx >= 0)) sweep_spheres_bvh<SHADOW, STATS>(tab, order_of, w, o, d, dd, shadow_margin, s, cs, ctr);
     } else if (STREAM) {
@@ -1169,7 +1170,7 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
 #endif
     } else {
         sweep_group<kSphereAxis, SHADOW, STATS>(tab, order_of, w.group[0], w.group[1], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
-        sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
+        if (!SLIM) sweep_group<kSphereGeneral, SHADOW, STATS>(tab, order_of, w.group[1], w.group[2], o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     }
     if (!SHADOW) {
         s.top1 = cs.i[0][tid];
@@ -1295,7 +1296,7 @@ __device__ __forceinline__ WorldArg world_argument() {
 // The read-only tables and the output are separate __restrict__ kernel arguments so that
 // the compiler can prove the wave-uniform table reads are never clobbered by the kernel's
 // own stores and keep them on the scalar path; the structs carry the remaining scalars.
-// TABLES: 0 = per-hit tables gathered from global memory, 1 = from their LDS copy (small
+// TABLES: 3 = as 1, for worlds without cubes and general spheres (launch_variant); 0 = per-hit tables gathered from global memory, 1 = from their LDS copy (small
 // worlds), 2 = global memory and the spheres swept through the hierarchy.
 template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
 __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_WAVES_PER_EU) void render_kernel(const double* __restrict__ g_tab,
@@ -1311,7 +1312,8 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
                                                         const float* __restrict__ g_pairs_r,
                                                         const float* __restrict__ g_pairs_s, const DevWorld wc,
                                                         const DevJob job) {
-    constexpr bool LDS = TABLES == 1;
+    constexpr bool LDS = TABLES == 1 || TABLES == 3;
+    constexpr bool SLIM = TABLES == 3;  // (see launch_variant)
     constexpr bool ACCEL = TABLES == 2;
     constexpr bool STREAM = TABLES == 0;  // large world, list walk: the spheres' bounds are streamed from their side tables
     __shared__ ContainerSlots containers;
@@ -1540,7 +1542,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
 #endif
             const int remaining = ((aux >> kAuxRemShift) & 63) - sp;
             Sweep hit;
-            sweep_world<false, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_r, g_pairs_r, w, ro, rd, hit, containers, ctr);
+            sweep_world<false, STATS, ACCEL, STREAM, SLIM>(sweep_tab, g_order, g_bounds_r, g_pairs_r, w, ro, rd, hit, containers, ctr);
             RTC_STAMP(pc_sweep1);
 
             have_ret = true;
@@ -1702,7 +1704,8 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     uint32_t* __restrict__ g_counter, unsigned long long* __restrict__ g_stats, const double* __restrict__ g_bounds_r,
     const double* __restrict__ g_bounds_s, const double* __restrict__ g_inv, const float* __restrict__ g_pairs_r,
     const float* __restrict__ g_pairs_s, const DevWorld wc, const DevJob job) {
-    constexpr bool LDS = TABLES == 1;
+    constexpr bool LDS = TABLES == 1 || TABLES == 3;
+    constexpr bool SLIM = TABLES == 3;  // (see launch_variant)
     constexpr bool ACCEL = TABLES == 2;
     constexpr bool STREAM = TABLES == 0;
     __shared__ ContainerSlots containers;
@@ -1843,7 +1846,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
             if (STATS) ++n_radiance;
             const int remaining = rem;
             Sweep hit;
-            sweep_world<false, STATS, ACCEL, STREAM>(sweep_tab, g_order, g_bounds_r, g_pairs_r, w, ro, rd, hit, containers, ctr);
+            sweep_world<false, STATS, ACCEL, STREAM, SLIM>(sweep_tab, g_order, g_bounds_r, g_pairs_r, w, ro, rd, hit, containers, ctr);
             bool chain_ends = true;  // a miss adds Color.Black (calc.zig:650)
             if (hit.idx >= 0) {
 #include "rtc_node.inc"
@@ -2023,7 +2026,16 @@ hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t s
 template <int MAXD, bool STATS, bool FROM_RAYS>
 hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t stream) {
     if (world.bvh) return launch_tables<MAXD, STATS, FROM_RAYS, 2>(world, job, stream);
-    if (world.n <= kLdsShapes) return launch_tables<MAXD, STATS, FROM_RAYS, 1>(world, job, stream);
+    if (world.n <= kLdsShapes) {
+        // A world whose spheres all have diagonal inverses and that holds no cube (the reference's own scenes) gets
+        // kernels without the loops and the normal arithmetic of the general kinds: TABLES == 3.  Only the frame
+        // kernels (no statistics, camera rays) exist in that form.
+        if constexpr (!STATS && !FROM_RAYS) {
+            if (world.group[1] == world.group[2] && world.group[4] == world.group[5])
+                return launch_tables<MAXD, STATS, FROM_RAYS, 3>(world, job, stream);
+        }
+        return launch_tables<MAXD, STATS, FROM_RAYS, 1>(world, job, stream);
+    }
     return launch_tables<MAXD, STATS, FROM_RAYS, 0>(world, job, stream);
 }
 
