@@ -409,6 +409,29 @@ def test_worlds_beyond_the_lds_table_size_and_one_kind_worlds():
     assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), "planes only")
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_worlds_of_axis_aligned_ellipsoids(seed):
+    """Worlds whose spheres are stretched along the axes only (diagonal inverses, as every sphere of the reference's
+    scenes) are rendered by frame kernels compiled without the loops of the general kinds and with the normal's
+    products with exact zeros left out.  Glass, mirrors, patterns, depth 5: the literal integrator's canvas, by both
+    integrators (the weighted one at the stated tolerance) and in a partition."""
+    w, c = random_world(seed, n_spheres=9, n_planes=3, axis_only=True)
+    want = O.render(w, c, 5, O.LITERAL)
+    assert_identical(c.render(w, 5).pixels, want, f"axis-aligned ellipsoids, seed {seed}")
+    cd = c.desc()
+    with scene_of(w) as sc:
+        assert sc.group_counts()[1] == 0 and sc.group_counts()[4] == 0
+        st = D.RtcStats()
+        assert_identical(sc.render(cd, 5, st), want, "statistics build (general kernels)")
+        sc.set_integrator(D.RTC_INTEGRATOR_WEIGHTED)
+        got = sc.render(cd, 5)
+        fin = np.isfinite(want)
+        scale = max(1.0, float(np.abs(want[fin]).max(initial=0.0)))
+        assert np.array_equal(np.isfinite(got), fin) and np.abs(got[fin] - want[fin]).max(initial=0.0) <= TOL * scale
+        sc.set_integrator(D.RTC_INTEGRATOR_POSTORDER)
+        assert_identical(sc.render(cd, 16), O.render(w, c, 16, O.STREAMING), "depth 16")
+
+
 def test_nested_glass_world():
     w, c = nested_glass_world()
     assert_identical(c.render(w, 5).pixels, O.render(w, c, 5, O.LITERAL), "nested glass")

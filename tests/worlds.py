@@ -7,7 +7,10 @@ from raytracer_challenge_amd import (Camera, Color, Mat4, Material, Pattern, Poi
                                      init_vector, view_transform)
 
 
-def random_world(seed, n_spheres=6, n_planes=2, glass=True, n_cubes=0):
+def random_world(seed, n_spheres=6, n_planes=2, glass=True, n_cubes=0, axis_only=False):
+    """axis_only: the spheres are ellipsoids along the axes (scale and translation only: diagonal inverses) and every
+    shininess is an integer, as in the reference's own scenes; such worlds of at most 32 shapes are rendered by the
+    kernels without the general kinds."""
     rng = np.random.default_rng(seed)
     u = lambda lo, hi: float(rng.uniform(lo, hi))
     w = World()
@@ -39,8 +42,11 @@ def random_world(seed, n_spheres=6, n_planes=2, glass=True, n_cubes=0):
         t = Mat4.identity().rotate_x(u(-0.3, 0.3)).rotate_z(u(-0.3, 0.3)).translate(0, u(-3, -1) if i == 0 else u(6, 9), 0)
         w.objects.append(Shape("plane", t, rand_material(i)))
     for i in range(n_spheres):
-        t = (Mat4.identity().scale(u(0.3, 1.5), u(0.3, 1.5), u(0.3, 1.5)).rotate_y(u(0, 3))
-             .shear(u(-0.2, 0.2), 0, 0, u(-0.2, 0.2), 0, 0).translate(u(-3, 3), u(-1, 3), u(-2, 4)))
+        if axis_only:
+            t = Mat4.identity().scale(u(0.3, 1.5), u(0.3, 1.5), u(0.3, 1.5)).translate(u(-3, 3), u(-1, 3), u(-2, 4))
+        else:
+            t = (Mat4.identity().scale(u(0.3, 1.5), u(0.3, 1.5), u(0.3, 1.5)).rotate_y(u(0, 3))
+                 .shear(u(-0.2, 0.2), 0, 0, u(-0.2, 0.2), 0, 0).translate(u(-3, 3), u(-1, 3), u(-2, 4)))
         w.objects.append(Shape("sphere", t, rand_material(i)))
     for i in range(n_cubes):  # the library's extension beyond the reference's two kinds
         t = (Mat4.identity().scale(u(0.2, 1.2), u(0.2, 1.2), u(0.2, 1.2)).rotate_y(u(0, 3)).rotate_x(u(-0.5, 0.5))
