@@ -863,7 +863,7 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                                                     int begin, int end, const V3& o, const V3& d, double dd,
                                                     double shadow_margin, uint32_t block_pairs_offset,
                                                     uint32_t super_pairs_offset, uint32_t group_pairs_offset, int top_log2,
-                                                    uint32_t order_mask, double block_shrink, double block_margin_scale, Sweep& s,
+                                                    uint32_t order_mask, bool all_diagonal, double block_shrink, double block_margin_scale, Sweep& s,
                                                     ContainerSlots& cs, SweepCounters& ctr) {
     if (begin >= end) return;
     Ray32 r32 = ray_in_floats<SHADOW>(o, d, dd, shadow_margin);
@@ -969,10 +969,16 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                     if (!clear) {
                         ShapeRec rec;
                         const double* __restrict__ m = inv + (size_t)(uint32_t)i * 12;
-#pragma unroll
-                        for (int k = 0; k < 12; ++k) rec.m[k] = m[k];
                         rec.order = order_of[i];
-                        sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                        if (all_diagonal) {
+                            // (wave-uniform: no sphere of the world has an off-diagonal entry; six loads instead of twelve)
+                            rec.m[0] = m[0], rec.m[3] = m[3], rec.m[5] = m[5], rec.m[7] = m[7], rec.m[10] = m[10], rec.m[11] = m[11];
+                            sweep_shape<kSphereAxis, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 12; ++k) rec.m[k] = m[k];
+                            sweep_shape<kSphereGeneral, SHADOW, STATS, true>(rec, i, order_of, o, d, dd, 0.0, shadow_margin, s, cs, ctr);
+                        }
                         if (!SHADOW) r32.lim = reach();
                     }
                 }
@@ -1162,7 +1168,7 @@ __device__ __forceinline__ void sweep_world(const double* __restrict__ tab, cons
                                            SHADOW ? 0u
                                                   : (d.x < 0 ? w.sweep_axis_mask[0] : 0u) | (d.y < 0 ? w.sweep_axis_mask[1] : 0u) |
                                                         (d.z < 0 ? w.sweep_axis_mask[2] : 0u),
-                                           w.block_shrink, w.block_margin_scale, s, cs, ctr);
+                                           w.group[1] == w.group[2], w.block_shrink, w.block_margin_scale, s, cs, ctr);
 #else
         sweep_spheres_streamed<SHADOW, STATS>(sphere_pairs, sphere_bounds, tab, order_of, w.group[0], w.group[1], w.group[2], o, d, dd,
                                               shadow_margin, SHADOW ? w.block_pairs_offset_shadow : w.block_pairs_offset_radiance,
