@@ -40,7 +40,10 @@ constexpr int kRecAxisPlaneM = 0, kRecAxisPlaneOrder = 2, kRecAxisPlaneLight = 4
 constexpr int kRecPlaneM = 0, kRecPlaneOrder = 4, kRecPlaneLight = 5;
 constexpr int kRecFullOrder = 12, kRecFullBound = 13, kRecFullLight = 20;
 constexpr int kSphereBoundsPadding = 80;  // entries the streamed sweep may read past the last sphere (a block of 64 and the read-ahead)
-constexpr int kLdsShapeLimit = 32;        // worlds of at most this many shapes keep their per-hit tables in LDS
+#ifndef RTC_LDS_SHAPES
+#define RTC_LDS_SHAPES 32
+#endif
+constexpr int kLdsShapeLimit = RTC_LDS_SHAPES;  // worlds of at most this many shapes keep their per-hit tables in LDS
 constexpr int kSphereBlock = 8;           // spheres per block of the streamed sweep's block test
 constexpr int kRecordDoubles = 24;  // doubles per sweep-table record (see DevWorld)
 

@@ -575,6 +575,11 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
 // only wait is "all of them": each record is consumed first (that wait covers only its own
 // loads), then the record after the next is requested and stays in flight during the
 // arithmetic.  The two record buffers alternate, so no register copies are needed.
+#ifdef RTC_LDS_SWEEP
+#define RTC_RECORD_ARRIVED(x) asm volatile("" ::"v"(x) : "memory")
+#else
+#define RTC_RECORD_ARRIVED(x) asm volatile("" ::"s"(x) : "memory")
+#endif
 template <int KIND, bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, const int* __restrict__ order_of, int begin,
                                             int end, const V3& o, const V3& d, double dd, double side_scale, double shadow_margin, Sweep& s,
@@ -582,10 +587,10 @@ __device__ __forceinline__ void sweep_group(const double* __restrict__ tab, cons
     if (begin >= end) return;
     ShapeRec A = load_rec<KIND, SHADOW>(tab, begin);
     for (int i = begin; i < end; i += 2) {
-        asm volatile("" ::"s"(A.m[5]) : "memory");  // (an entry every layout loads)
+        RTC_RECORD_ARRIVED(A.m[5]);  // (an entry every layout loads)
         const ShapeRec B = load_rec<KIND, SHADOW>(tab, i + 1);
         sweep_shape<KIND, SHADOW, STATS>(A, i, order_of, o, d, dd, side_scale, shadow_margin, s, cs, ctr);
-        asm volatile("" ::"s"(B.m[5]) : "memory");
+        RTC_RECORD_ARRIVED(B.m[5]);
         A = load_rec<KIND, SHADOW>(tab, i + 2);
         if (i + 1 < end) sweep_shape<KIND, SHADOW, STATS>(B, i + 1, order_of, o, d, dd, side_scale, shadow_margin, s, cs, ctr);
     }
@@ -1261,13 +1266,19 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
 // and its material/pattern record) in LDS, copied once per workgroup: a gather then costs an
 // LDS access instead of a chain of dependent trips to the L2, which four waves per SIMD
 // cannot hide.  Larger worlds spend their time in the sweeps and gather from global memory.
-constexpr int kLdsShapes = 32;
+constexpr int kLdsShapes = kLdsShapeLimit;
 template <bool ON>
 struct HotTables {};
 template <>
 struct HotTables<true> {
     double mat[kLdsShapes][12];
     DevShade shade[kLdsShapes];
+#ifdef RTC_LDS_SWEEP
+    // developer switch, for comparison (build with -DRTC_LDS_SHAPES=16 so that the workgroup's LDS still allows four per
+    // CU): the sweep table in LDS too, read with wave-uniform LDS addresses - a broadcast into VECTOR registers - instead
+    // of scalar loads into scalar registers
+    double tab[(kLdsShapes + 2) * kRecDoubles];
+#endif
 };
 static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
 
@@ -1346,7 +1357,16 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
         else
             return g_inv + (size_t)i * 12;
     };
+#ifdef RTC_LDS_SWEEP
+    const double* sweep_tab = g_tab;
+    if constexpr (LDS) {
+        for (int k = (int)threadIdx.x; k < (wc.n + 2) * kRecDoubles; k += kBlock) hot.tab[k] = g_tab[k];
+        __syncthreads();
+        sweep_tab = hot.tab;
+    }
+#else
     const double* __restrict__ sweep_tab = g_tab;
+#endif
     const int lane = (int)(threadIdx.x & 63);
     DevWorld w = wc;
     w.tab = g_tab;
