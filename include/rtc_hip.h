@@ -238,17 +238,31 @@ int rtc_render_device(RtcScene* scene, const RtcCameraDesc* camera, int32_t dept
                       RtcStats* stats);
 
 /* rtc_render_device for callers that cannot allocate device memory.  This entry point has no
- * counterpart in the reference; it exists for callers that must not call hipMalloc: code under
- * HIP graph capture, tight serving loops, harnesses that forbid allocation.  It renders exactly
- * what rtc_render_device renders (same arguments, same output layout, same values) but keeps the
- * launch's scratch data — the control block with the work-queue heads and statistics counters,
- * and the queue plan of one uint32 per local tile — in a fixed array in the library's device
- * image instead of buffers of the scene, and calls no hipMalloc / hipFree or other allocating
- * routine.  Limit: at most RTC_NOALLOC_MAX_TILES local tiles (tiles of this rank's share:
- * 7680x4320 on one rank is 64 800), RTC_ERR_TOO_LARGE beyond.  The array (about 1 MiB) exists
- * once per GPU and is shared by every call on that GPU, whatever the scene: calls that overlap
- * on one GPU (two streams, two threads) race on it and must be serialised by the caller.  The
- * scene itself must have been created before (rtc_scene_create allocates). */
+ * counterpart in the reference; it exists for callers that must not call hipMalloc: tight serving
+ * loops, harnesses that forbid allocation, code under HIP graph capture.  It renders exactly what
+ * rtc_render_device renders (same arguments, same output layout, same values) but keeps the
+ * launch's scratch data - the control block with the work-queue heads and statistics counters,
+ * and the queue plan of one uint32 per local tile - in a fixed array in the library's device
+ * image instead of buffers of the scene, and calls no hipMalloc / hipFree or other routine that
+ * allocates device memory.  Limit: at most RTC_NOALLOC_MAX_TILES local tiles (tiles of this rank's
+ * share: 7680x4320 on one rank is 64 800), RTC_ERR_TOO_LARGE beyond.
+ * Without statistics the call only enqueues work on hip_stream (a memset of the control block, an
+ * upload of the queue plan when scene, camera or partition differ from the previous call on this
+ * GPU, the kernel) and never waits for the device, except that a changed plan first waits for the
+ * previous plan's UPLOAD to have left the host.  With stats != NULL it synchronises like
+ * rtc_render_device.
+ * While hip_stream is being captured into a graph: stats must be NULL (RTC_ERR_INVALID_ARGUMENT
+ * otherwise); the launch uses the natural queue order instead of a plan, because a plan would live
+ * in the shared array, which later calls may overwrite before the graph runs (same pixels, a
+ * schedule a few per cent slower on frames with transparent shapes); the captured nodes are the
+ * memset and the kernel, and the graph may be replayed any number of times as long as scene, output
+ * buffer and stream ordering stay valid.
+ * The array (about 1 MiB) exists once per GPU and is shared by every call on that GPU, whatever the
+ * scene: launches that overlap on one GPU (two streams, two threads, a replayed graph beside a
+ * direct call) race on it - the later one resets the queue heads the earlier one is still drawing
+ * from - and must be serialised by the caller: the previous launch complete, or ordered before the
+ * next one on the same stream.  The scene itself must have been created before (rtc_scene_create
+ * allocates, and is where the library resolves the array's device address for the current GPU). */
 #define RTC_NOALLOC_MAX_TILES 262144
 int rtc_render_device_noalloc(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth,
                               uint32_t tile_rank, uint32_t tile_ranks, void* d_out_rgb,

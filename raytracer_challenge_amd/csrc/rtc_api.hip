@@ -183,6 +183,7 @@ bool valid_stream_and_ptr(const void* p) { return p != nullptr; }
 // ---- the opaque scene ---------------------------------------------------------------------
 struct RtcScene {
     int device = 0;
+    uint64_t serial = 0;  // unique per rtc_scene_create in this process (an address can be reused, a serial is not)
     uint64_t n = 0;
     uint64_t n_spheres = 0, n_planes = 0, n_cubes = 0;
     double* d_tab = nullptr;
@@ -908,7 +909,7 @@ int copy_canvas_to_host(RtcScene* s, const void* d_src, void* dst, size_t bytes)
 // Common launch path of rtc_render_device / rtc_render / rtc_color_at.
 // `control` is the launch's control block: the scene's own (nullptr) or the caller's.
 int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, uint64_t pixels,
-            uint32_t* control = nullptr) {
+            uint32_t* control = nullptr, bool zero_with_kernel = false) {
     if (job.depth > rtc::kMaxDepthLarge) {
         char buf[96];
         std::snprintf(buf, sizeof buf, "depth %d exceeds the supported maximum %d", job.depth, rtc::kMaxDepthLarge);
@@ -941,8 +942,12 @@ int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, 
         }
         return RTC_OK;
     }
-    // zero the queue head and the stats words
-    HIP_TRY(hipMemsetAsync(control, 0, rtc::kProbeOffsetBytes, stream));
+    // zero the queue heads and the stats words (a launch captured into a graph does it with a kernel node: a
+    // captured memset node of this block was seen not to run when the graph was replayed)
+    if (zero_with_kernel)
+        HIP_TRY(rtc::launch_zero_words(control, rtc::kProbeOffsetBytes / 4, stream));
+    else
+        HIP_TRY(hipMemsetAsync(control, 0, rtc::kProbeOffsetBytes, stream));
     if (stats) HIP_TRY(hipEventRecord(s->ev_start, stream));
     HIP_TRY(rtc::launch_render(dev_world(s), job, stats != nullptr, stream));
     if (stats) {
@@ -1003,25 +1008,31 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
 struct ScratchSlot {
     unsigned char* ptr = nullptr;  // device address of this device's copy of `scratch`
-    // the plan the copy holds: scene, camera and partition it was computed for
+    // the plan the copy holds: scene (by serial number), camera and partition it was computed for
     bool plan_valid = false, plan_identity = true;
-    const RtcScene* plan_scene = nullptr;
+    uint64_t plan_scene_serial = 0;
     RtcCameraDesc plan_camera{};
     uint32_t plan_rank = 0, plan_ranks = 0;
+    // host copy of that plan: the source of the asynchronous upload, which must outlive the call; the event
+    // (created with the slot, at set-up) marks the end of the last upload, after which the copy may change
+    std::vector<uint32_t> host_plan;
+    hipEvent_t uploaded = nullptr;
+    bool upload_pending = false;
 };
 ScratchSlot g_scratch_slots[kMaxDevices];
-std::mutex g_scratch_mutex;
+std::mutex g_scratch_mutex;  // held by rtc_render_device_noalloc from the look at the slot to the launch
 
+// (the caller holds g_scratch_mutex)
 int scratch_of_current_device(ScratchSlot** out) {
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices) return fail(RTC_ERR_TOO_LARGE, "device index beyond the scratch table");
-    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     ScratchSlot& slot = g_scratch_slots[dev];
     if (!slot.ptr) {
         void* p = nullptr;
         HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         if (!p) return fail(RTC_ERR_DEVICE, "hipGetSymbolAddress(scratch) returned NULL");
+        HIP_TRY(hipEventCreateWithFlags(&slot.uploaded, hipEventDisableTiming));
         slot.ptr = (unsigned char*)p;
     }
     *out = &slot;
@@ -1310,6 +1321,10 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
 
     RtcScene* sc = new (std::nothrow) RtcScene();
     if (!sc) return fail(RTC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    {
+        static std::atomic<uint64_t> next_serial{1};
+        sc->serial = next_serial.fetch_add(1);
+    }
     hipError_t e = hipGetDevice(&sc->device);
     if (e != hipSuccess) {
         free_scene(sc);
@@ -1452,17 +1467,21 @@ int rtc_scene_create(const RtcShapeDesc* shapes, uint64_t n_shapes, const RtcLig
         SCENE_TRY(hipMemcpy(sc->d_shade, shade_tab.data(), n_shapes * sizeof(rtc::DevShade), hipMemcpyHostToDevice));
     std::memcpy(sc->group, group, sizeof group);
 #undef SCENE_TRY
+    {
+        // set-up time is where the library learns the device address of its fixed scratch array on this GPU
+        // (rtc_render_device_noalloc then finds it resolved, also when its stream is being captured)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        ScratchSlot* slot = nullptr;
+        if (int rc = scratch_of_current_device(&slot)) {
+            free_scene(sc);
+            return rc;
+        }
+    }
     *out_scene = sc;
     return RTC_OK;
 }
 
 int rtc_scene_destroy(RtcScene* scene) {
-    {
-        // a later scene may be allocated at the same address: forget the plans kept for this one
-        std::lock_guard<std::mutex> lock(g_scratch_mutex);
-        for (ScratchSlot& slot : g_scratch_slots)
-            if (slot.plan_scene == scene) slot.plan_valid = false;
-    }
     free_scene(scene);
     return RTC_OK;
 }
@@ -1614,36 +1633,55 @@ int rtc_render_device_noalloc(RtcScene* scene, const RtcCameraDesc* camera, int3
     }
     job.out = (double*)d_out_rgb;
     hipStream_t stream = (hipStream_t)hip_stream;
+    // While the stream is being captured into a graph nothing here may wait for the device or copy from the
+    // host, and whatever the launch reads must still be there when the graph runs, any number of times, after
+    // other calls have used the array: the captured launch takes the natural queue order (it reads no plan;
+    // every pixel gets the same value, only the schedule differs), and statistics, which need a host
+    // synchronisation, are refused.
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    HIP_TRY(hipStreamIsCapturing(stream, &capture));
+    const bool capturing = capture != hipStreamCaptureStatusNone;
+    if (capturing && stats)
+        return fail(RTC_ERR_INVALID_ARGUMENT,
+                    "rtc_render_device_noalloc: statistics need a host synchronisation, which a capturing stream cannot give");
+    // one host thread at a time from here to the launch: the slot's bookkeeping and the order of the
+    // operations enqueued on the array (memset, plan upload, kernel) stay consistent
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     ScratchSlot* slot = nullptr;
     if (int rc = scratch_of_current_device(&slot)) return rc;
     uint32_t* control = (uint32_t*)slot->ptr;
     uint32_t* d_plan = (uint32_t*)(slot->ptr + kScratchControlBytes);
-    // queue plan: same arithmetic as rtc_render_device, kept in the scratch array instead of a
-    // buffer of the scene; the array remembers which scene, camera and partition it serves
+    // queue plan: same arithmetic as rtc_render_device, kept in the scratch array instead of a buffer of the
+    // scene; the slot remembers which scene, camera and partition the array's plan serves
     job.tile_order = nullptr;
-    if (!(local_tiles < 2 || scene->costly_everywhere || scene->costly.empty())) {
-        const bool cached = slot->plan_valid && slot->plan_scene == scene && slot->plan_rank == tile_rank &&
+    if (!capturing && !(local_tiles < 2 || scene->costly_everywhere || scene->costly.empty())) {
+        const bool cached = slot->plan_valid && slot->plan_scene_serial == scene->serial && slot->plan_rank == tile_rank &&
                             slot->plan_ranks == tile_ranks && std::memcmp(&slot->plan_camera, camera, sizeof *camera) == 0;
         if (!cached) {
-            std::vector<uint32_t> order;
-            if (int rc = compute_tile_order(scene, camera, &job, local_tiles, order)) return rc;
             slot->plan_valid = false;
-            if (!order.empty()) {
-                // an earlier launch on this stream may still be reading the previous plan
-                HIP_TRY(hipStreamSynchronize(stream));
-                HIP_TRY(hipMemcpy(d_plan, order.data(), local_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if (slot->upload_pending) {  // the last upload may still be reading the host copy
+                HIP_TRY(hipEventSynchronize(slot->uploaded));
+                slot->upload_pending = false;
             }
-            slot->plan_scene = scene;
+            if (int rc = compute_tile_order(scene, camera, &job, local_tiles, slot->host_plan)) return rc;
+            // Stream-ordered upload: it runs after whatever this stream still has to do with the previous plan, and
+            // the kernel below runs after it.  (Launches on OTHER streams must not overlap this call: see the header.)
+            if (!slot->host_plan.empty()) {
+                HIP_TRY(hipMemcpyAsync(d_plan, slot->host_plan.data(), local_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipEventRecord(slot->uploaded, stream));
+                slot->upload_pending = true;
+            }
+            slot->plan_scene_serial = scene->serial;
             slot->plan_camera = *camera;
             slot->plan_rank = tile_rank;
             slot->plan_ranks = tile_ranks;
-            slot->plan_identity = order.empty();
+            slot->plan_identity = slot->host_plan.empty();
             slot->plan_valid = true;
         }
         job.tile_order = slot->plan_identity ? nullptr : d_plan;
     }
     const uint64_t pixels = tile_ranks == 1 ? camera->hsize * camera->vsize : local_pixels;
-    return run_job(scene, job, stream, stats, pixels, control);
+    return run_job(scene, job, stream, stats, pixels, control, capturing);
 }
 
 int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, double* out_rgb, RtcStats* stats) {

@@ -199,6 +199,7 @@ hipError_t launch_scatter_tiles(const double* tiles, uint32_t tile_rank, uint32_
 hipError_t launch_scatter_tiles_u8(const uint8_t* tiles, uint32_t tile_rank, uint32_t tile_ranks, uint32_t hsize,
                                    uint32_t vsize, uint8_t* canvas, hipStream_t stream);
 hipError_t launch_quantize(const double* rgb, uint64_t n, uint8_t* out, hipStream_t stream);
+hipError_t launch_zero_words(uint32_t* p, uint32_t words, hipStream_t stream);
 hipError_t launch_arith_probe(const double* a, const double* b, uint64_t n, double* out_div, double* out_sqrt,
                               double* out_pow, hipStream_t stream);
 

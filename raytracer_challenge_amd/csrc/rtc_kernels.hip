@@ -2144,6 +2144,15 @@ hipError_t launch_quantize(const double* rgb, uint64_t n, uint8_t* out, hipStrea
     return hipGetLastError();
 }
 
+// Zeroes `words` 32-bit words (the control block of a launch).
+__global__ __launch_bounds__(kBlock) void zero_words_kernel(uint32_t* __restrict__ p, uint32_t words) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+hipError_t launch_zero_words(uint32_t* p, uint32_t words, hipStream_t stream) {
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(kBlock), 0, stream, p, words);
+    return hipGetLastError();
+}
+
 hipError_t launch_arith_probe(const double* a, const double* b, uint64_t n, double* out_div, double* out_sqrt,
                               double* out_pow, hipStream_t stream) {
     uint64_t blocks = (n + kBlock - 1) / kBlock;

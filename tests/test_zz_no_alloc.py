@@ -67,3 +67,78 @@ def test_no_alloc_entry_point_refuses_more_tiles_than_its_array_holds():
         assert e.value.code == D.RTC_ERR_TOO_LARGE
         # split over two ranks the share fits (and is refused for the NULL-free reason only):
         # not launched here, the output buffer would be 2.3 GB
+
+
+def test_no_alloc_entry_point_under_graph_capture():
+    """The call is captured into a HIP graph (memset of the control block + the kernel, nothing that waits
+    or copies from the host) and the graph, replayed, draws what rtc_render_device draws - also after
+    other calls have put another camera's plan into the shared array."""
+    import ctypes as C
+
+    import torch
+
+    hip = C.CDLL("libamdhip64.so")
+
+    def ok(rc, what):
+        assert rc == 0, f"{what} returned {rc}"
+
+    dev = torch.device("cuda", 0)
+    w, cam = scenes.draw_world_scene(640, 360)
+    _, other = scenes.draw_world_scene(333, 97)
+    cd = cam.desc()
+    n = native.tile_buffer_doubles(cd, 0, 1)
+    with native.Scene(w.shape_descs(), len(w.objects), w.light_desc()) as sc:
+        want = torch.empty(n, dtype=torch.float64, device=dev)
+        sc.render_device(cd, 5, want.data_ptr())
+        got = torch.full((n,), -7.0, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        stream = C.c_void_p()
+        ok(hip.hipStreamCreate(C.byref(stream)), "hipStreamCreate")
+        graph, graph_exec = C.c_void_p(), C.c_void_p()
+        ok(hip.hipStreamBeginCapture(stream, 1), "hipStreamBeginCapture")  # hipStreamCaptureModeThreadLocal
+        try:
+            # statistics would need a host synchronisation: refused before anything touches the stream
+            with pytest.raises(native.RtcError) as e:
+                sc.render_device_noalloc(cd, 5, got.data_ptr(), 0, 1, stream, D.RtcStats())
+            assert e.value.code == D.RTC_ERR_INVALID_ARGUMENT
+            sc.render_device_noalloc(cd, 5, got.data_ptr(), 0, 1, stream)
+        finally:
+            ok(hip.hipStreamEndCapture(stream, C.byref(graph)), "hipStreamEndCapture")
+        assert graph.value, "the capture was invalidated"
+        ok(hip.hipGraphInstantiate(C.byref(graph_exec), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
+        # nothing ran during the capture
+        assert torch.all(got == -7.0)
+        for replay in range(3):
+            got.fill_(-7.0)
+            torch.cuda.synchronize()
+            ok(hip.hipGraphLaunch(graph_exec, stream), "hipGraphLaunch")
+            ok(hip.hipStreamSynchronize(stream), "hipStreamSynchronize")
+            assert torch.equal(got, want), f"replay {replay}"
+            # a direct call with another camera replaces the plan in the shared array; the graph reads none
+            small = torch.empty(native.tile_buffer_doubles(other.desc(), 0, 1), dtype=torch.float64, device=dev)
+            sc.render_device_noalloc(other.desc(), 5, small.data_ptr())
+            torch.cuda.synchronize()
+        ok(hip.hipGraphExecDestroy(graph_exec), "hipGraphExecDestroy")
+        ok(hip.hipGraphDestroy(graph), "hipGraphDestroy")
+        ok(hip.hipStreamDestroy(stream), "hipStreamDestroy")
+
+
+def test_no_alloc_plan_is_not_reused_for_a_new_scene_at_the_same_address():
+    """The cached plan is keyed on the scene's serial number: scenes created and destroyed in a row (the
+    allocator may hand out the same address) each get their own."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    for k in range(4):
+        w, cam = scenes.draw_world_scene(256, 128)
+        if k % 2:
+            w.objects = w.objects[:11]  # without the glass spheres: another plan for the same camera
+        cd = cam.desc()
+        with native.Scene(w.shape_descs(), len(w.objects), w.light_desc()) as sc:
+            n = native.tile_buffer_doubles(cd, 0, 1)
+            want = torch.empty(n, dtype=torch.float64, device=dev)
+            got = torch.full((n,), -7.0, dtype=torch.float64, device=dev)
+            sc.render_device(cd, 5, want.data_ptr())
+            sc.render_device_noalloc(cd, 5, got.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
