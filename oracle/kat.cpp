@@ -721,6 +721,27 @@ int main() {
             CHECK(cubeLocalIntersect(Ray{initPoint(c[0], c[1], c[2]), initVector(c[3], c[4], c[5])}, ts) == 0);
         }
     });
+    run("extension: rays that lie in a face plane of the cube (parallel to an axis, origin on the slab's plane)", [] {
+        // the decision of cubeCheckAxis: the face plane belongs to the cube, whichever axis it is across.  Columns:
+        // origin, direction, expected number of t, t0, t1.
+        const double cases[12][9] = {
+            {-1, 0.5, -5, 0, 0, 1, 2, 4, 6},   {1, 0.5, -5, 0, 0, 1, 2, 4, 6},    // in the planes x = -1 / x = 1, along z
+            {0.5, -1, -5, 0, 0, 1, 2, 4, 6},   {0.5, 1, -5, 0, 0, 1, 2, 4, 6},    // y = -1 / y = 1, along z
+            {-5, 0.2, -1, 1, 0, 0, 2, 4, 6},   {-5, 0.2, 1, 1, 0, 0, 2, 4, 6},    // z = -1 / z = 1, along x
+            {0.3, -5, 1, 0, 1, 0, 2, 4, 6},    {1, -5, 0.3, 0, 1, 0, 2, 4, 6},    // z = 1 / x = 1, along y
+            {-1, -1, -5, 0, 0, 1, 2, 4, 6},                                        // along an edge
+            {-1, 1.5, -5, 0, 0, 1, 0, 0, 0},   {0.5, -1, 3, 1, 0, 0, 0, 0, 0},    // in a face plane but beside the cube
+            {1, 1, 0, 0, 0, -1, 2, -1, 1}};                                        // on an edge, from the middle of it
+        for (const auto& c : cases) {
+            double ts[2] = {0, 0};
+            const int n = cubeLocalIntersect(Ray{initPoint(c[0], c[1], c[2]), initVector(c[3], c[4], c[5])}, ts);
+            CHECK(n == (int)c[6]);
+            if (n == 2) {
+                CHECK_EPS(c[7], ts[0]);
+                CHECK_EPS(c[8], ts[1]);
+            }
+        }
+    });
     run("extension (book Ch. 12, no reference counterpart): the normal on the surface of a cube", [] {
         const double cases[8][6] = {{1, 0.5, -0.8, 1, 0, 0},  {-1, -0.2, 0.9, -1, 0, 0}, {-0.4, 1, -0.1, 0, 1, 0},
                                     {0.3, -1, -0.7, 0, -1, 0}, {-0.6, 0.3, 1, 0, 0, 1},   {0.4, 0.4, -1, 0, 0, -1},

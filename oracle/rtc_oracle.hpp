@@ -547,8 +547,13 @@ inline void cubeCheckAxis(double origin, double direction, double* tmin, double*
         lo = tmin_numerator / direction;
         hi = tmax_numerator / direction;
     } else {
-        lo = tmin_numerator * std::numeric_limits<double>::infinity();
-        hi = tmax_numerator * std::numeric_limits<double>::infinity();
+        // A ray parallel to the slab: inside it for good (-inf, +inf) or outside for good.  With the origin exactly
+        // ON one of the two planes a numerator is zero and 0 * inf is not a number, which the comparisons below
+        // would keep or drop depending on the axis; the decision taken here: the face plane belongs to the cube, a
+        // zero numerator gets the bound it has for origins just inside (the same on all three axes).
+        const double inf = std::numeric_limits<double>::infinity();
+        lo = tmin_numerator == 0 ? -inf : tmin_numerator * inf;
+        hi = tmax_numerator == 0 ? inf : tmax_numerator * inf;
     }
     if (lo > hi) {
         const double t = lo;

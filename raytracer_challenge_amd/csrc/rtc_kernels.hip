@@ -369,8 +369,10 @@ __device__ __forceinline__ void cube_axis(double origin, double direction, doubl
     const double n0 = -1.0 - origin, n1 = 1.0 - origin;
     const bool parallel = !(fabs(direction) >= kF64Eps);
     const double inf = __builtin_huge_val();
-    const double a = parallel ? n0 * inf : n0 / direction;
-    const double b = parallel ? n1 * inf : n1 / direction;
+    // (parallel and the origin exactly on a face plane: 0 * inf would be a NaN; the face belongs to the cube, so
+    // a zero numerator gets the bound of an origin just inside - the oracle's cubeCheckAxis takes the same decision)
+    const double a = parallel ? (n0 == 0 ? -inf : n0 * inf) : n0 / direction;
+    const double b = parallel ? (n1 == 0 ? inf : n1 * inf) : n1 / direction;
     const bool swap = a > b;
     lo = swap ? b : a;
     hi = swap ? a : b;

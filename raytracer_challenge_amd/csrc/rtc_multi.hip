@@ -21,8 +21,6 @@
 // and rank 0's stream waits on an event per rank before the canvas is used.
 #include "rtc_internal.h"
 
-#include <rccl/rccl.h>
-
 #include <dlfcn.h>
 
 #include <chrono>
@@ -48,30 +46,47 @@ namespace {
     } while (0)
 
 // RCCL is loaded when the gather mode is first used: the other modes, and every single-GPU caller,
-// do not need the library present.
+// need neither the library nor its headers.  The few declarations used, as the library's C interface
+// publishes them (rccl.h: ncclResult_t 0 = success; ncclDataType_t ncclUint8 = 1, ncclFloat64 = 8):
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclUint8 = 1, ncclDouble = 8;
 struct Rccl {
     void* handle = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool loaded = false;  // every symbol below resolved
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    void unload() {
+        if (handle) (void)dlclose(handle);
+        handle = nullptr;
+        loaded = false;
+        CommInitAll = nullptr, CommDestroy = nullptr, GroupStart = nullptr, GroupEnd = nullptr, Send = nullptr, Recv = nullptr,
+        GetErrorString = nullptr;
+    }
     bool load(std::string* why) {
-        if (handle) return true;
+        if (loaded) return true;
+        unload();
         for (const char* name : {"librccl.so.1", "librccl.so"}) {
             handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (handle) break;
         }
         if (!handle) {
-            *why = std::string("dlopen(librccl.so.1): ") + dlerror();
+            const char* e = dlerror();
+            *why = std::string("dlopen(librccl.so.1): ") + (e ? e : "not found");
             return false;
         }
 #define RCCL_SYM(field, symbol)                                       \
     field = reinterpret_cast<decltype(field)>(dlsym(handle, symbol)); \
     if (!field) {                                                     \
         *why = std::string("librccl has no ") + symbol;               \
+        unload(); /* a later call starts over instead of calling through a null pointer */ \
         return false;                                                 \
     }
         RCCL_SYM(CommInitAll, "ncclCommInitAll")
@@ -82,6 +97,7 @@ struct Rccl {
         RCCL_SYM(Recv, "ncclRecv")
         RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef RCCL_SYM
+        loaded = true;
         return true;
     }
 };

@@ -609,6 +609,13 @@ def test_cubes_against_the_oracle():
                 d = [0.0, 0.0, 0.0]
                 d[axis] = sign
                 rays.append(list(o) + d)
+    # ... and rays that lie IN a face plane (origin exactly on a slab's plane, parallel to it): the face belongs to
+    # the cube on every axis (the oracle's cubeCheckAxis and the device's cube_axis take the same decision)
+    for o, d in (((-1, 0.5, -5), (0, 0, 1)), ((1, 0.5, -5), (0, 0, 1)), ((0.5, -1, -5), (0, 0, 1)), ((0.5, 1, -5), (0, 0, 1)),
+                 ((-5, 0.2, -1), (1, 0, 0)), ((-5, 0.2, 1), (1, 0, 0)), ((0.3, -5, 1), (0, 1, 0)), ((1, -5, 0.3), (0, 1, 0)),
+                 ((-1, -1, -5), (0, 0, 1)), ((-1, 1.5, -5), (0, 0, 1)), ((0.5, -1, 3), (1, 0, 0)), ((1, 1, 0), (0, 0, -1)),
+                 ((1, 0.2, 0.3), (0, 0, 1)), ((0.2, 1, 0.3), (1, 0, 0)), ((0.2, 0.3, -1), (0, 1, 0))):
+        rays.append([float(v) for v in o] + [float(v) for v in d])
     rays = np.array(rays)
     with scene_of(w) as sc:
         assert_identical(sc.color_at(rays, 5), O.color_at(w, rays, 5, O.LITERAL), "axis-parallel rays")

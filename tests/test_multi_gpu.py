@@ -148,11 +148,16 @@ def test_one_process_per_rank_front_end_with_ipc_canvas():
     import subprocess
     import sys
 
+    import socket
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sock:  # a port that is free now (not a constant another job on the box may hold)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     r = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
          "--workload", "c2", "--rehearse-on-one-gpu", "--verify"],
         capture_output=True, text=True, timeout=240, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
