@@ -635,12 +635,34 @@ def main():
             top = 512 if n_sph > 2048 else 64
             n_blocks = (n_sph + top - 1) // top
             f32 = (st.radiance_rays * 20 + st.shadow_rays * 10) * n_blocks
-            roofline["bound"] = "valu-issue (packed f32 pre-tests + f64)"
             roofline["f32_top_level_test_flops_per_launch"] = f32
             roofline["pairs_dismissed_by_f32_pre_tests"] = st.sphere_prefilter_skips / max(st.sphere_tests, 1)
-            roofline["note"] += (". In this workload the single-precision pre-tests dismiss most ray-sphere pairs "
-                                 "before any FP64 operation: `frac` (FP64 flops only) is then no measure of how busy "
-                                 "the vector units are; `counter_check.valu_busy` is")
+            # What bounds this kernel is the issue rate of the vector units, whatever the type of the instruction:
+            # `achieved` = vector wave-instructions x average active lanes per launch (hardware counters of the same
+            # command, profiles/pmc_counters.json) / the launch duration measured in THIS run; `peak` = 256 CUs x 64
+            # lanes x 2.4 GHz lane-operations per second.  The FP64 flop figures stay, as secondary ones.
+            fp64 = {k: roofline[k] for k in ("achieved", "frac", "executed_flops_per_launch", "algorithmic_flops_per_launch",
+                                              "achieved_algorithmic", "frac_algorithmic", "peak_with_fma", "frac_of_fma_peak")}
+            fp64["unit"] = "TFLOP/s"
+            fp64["peak"] = PEAK_FP64_NO_FMA_TFLOPS
+            for k in ("executed_flops_per_launch", "algorithmic_flops_per_launch", "achieved_algorithmic", "frac_algorithmic",
+                      "peak_with_fma", "frac_of_fma_peak"):
+                del roofline[k]
+            lane_ops = pmc["valu_wave_insts"] * pmc["active_lanes_per_valu_inst"] if pmc else None
+            roofline["bound"] = "valu-issue"
+            roofline["unit"] = "T lane-ops/s"
+            roofline["peak"] = PEAK_FP64_NO_FMA_TFLOPS  # the same 256 x 64 x 2.4e9 per second, counted in lane-operations
+            roofline["achieved"] = lane_ops / sec / 1e12 if lane_ops else None
+            roofline["frac"] = roofline["achieved"] / roofline["peak"] if lane_ops else None
+            roofline["valu_lane_ops_per_launch"] = lane_ops
+            roofline["fp64_flops_only"] = fp64
+            roofline["note"] = ("vector-issue bound: in a world too large for the on-chip tables nearly every ray-sphere pair "
+                                "ends in packed single-precision pre-tests (group of 512, super-block of 64, block of eight, "
+                                "sphere), integer bookkeeping of the per-lane work lists and per-lane loads, so FP64 flops "
+                                "describe a small part of the work (`fp64_flops_only`, 17 % of the vector instructions). "
+                                "`achieved` counts every vector instruction of a launch times its active lanes (hardware "
+                                "counters of this command, `counter_check.source`) over this run's launch duration; `frac` = "
+                                "share of the chip's lane-cycles that issue a vector operation = VALU busy x active lanes / 64")
             if "counter_check" in roofline:
                 # the few lanes that go on to the double test run it with most of the wave masked off, so
                 # wave-instructions x average lanes over-states the FP64 lane operations

@@ -428,6 +428,55 @@ int main() {
         }
     });
 
+    run("calc.zig:269-291 with two value-identical shapes: they toggle ONE container (std.meta.eql, calc.zig:274,280)", [] {
+        // The reference holds no test for this; it is what its container walk does, replayed by the LITERAL restatement:
+        // two coincident glass spheres that are equal field by field are "the same object" to the walk, so the second
+        // entry closes the container the first one opened.  Seen from inside both (t1 < 0 < t2 for each) the walk
+        // reaches the exit hit with NO open container: n1 = 1.0, and the hit sphere is then "entered": n2 = 1.5.
+        // Two spheres that differ in anything (here: the refractive index in its last bit) are two containers:
+        // n1 = the second's index, n2 = what remains after the first is removed.
+        Shape a = glassSphere();
+        const Shape twin = a;
+        const Ray r{initPoint(0, 0, 0), initVector(0, 0, 1)};
+        {
+            Intersections xs;
+            xs.list = {{-1, a}, {-1, twin}, {1, a}, {1, twin}};  // sorted by t, insertion order kept (ray.zig:89-92)
+            const Computations c = prepareComputations(xs.list[2], r, &xs);  // xs.hit(): the first t >= 0
+            CHECK_EPS(1.0, c.n1);
+            CHECK_EPS(1.5, c.n2);
+        }
+        {
+            Shape other = a;
+            other.material.refractive_index = std::nextafter(1.5, 2.0);
+            Intersections xs;
+            xs.list = {{-1, a}, {-1, other}, {1, a}, {1, other}};
+            const Computations c = prepareComputations(xs.list[2], r, &xs);
+            CHECK(c.n1 == other.material.refractive_index);
+            CHECK(c.n2 == other.material.refractive_index);
+        }
+        // through the integrators: the LITERAL one compares by value like the reference, the STREAMING one (the
+        // GPU's algorithm) identifies shapes by list index - which is why the library refuses such a world
+        // (RTC_ERR_DUPLICATE_SHAPE) instead of rendering it differently from the reference
+        World w;
+        w.light = PointLight{initPoint(-10, 10, -10), Color{1, 1, 1}};
+        w.objects.push_back(a);
+        w.objects.push_back(twin);
+        Shape floor = planeShape();
+        floor.transform = Mat4::identity().translate(0, -1.5, 0);
+        w.objects.push_back(floor);
+        w.prepare();  // (the hoisted inverses of the STREAMING integrator)
+        const Ray from_inside{initPoint(0, 0, 0.2), initVector(0.1, -0.3, 1).normalize()};
+        const Color lit = worldColorAt(w, from_inside, 5, LITERAL);
+        const Color str = worldColorAt(w, from_inside, 5, STREAMING);
+        CHECK(!(lit.red == str.red && lit.green == str.green && lit.blue == str.blue));
+        // with a single sphere the two integrators agree, as everywhere else
+        w.objects.erase(w.objects.begin() + 1);
+        w.prepare();
+        const Color lit1 = worldColorAt(w, from_inside, 5, LITERAL);
+        const Color str1 = worldColorAt(w, from_inside, 5, STREAMING);
+        CHECK(lit1.red == str1.red && lit1.green == str1.green && lit1.blue == str1.blue);
+    });
+
     // ------------------------------------------------------------ calc.zig shadeHit
     run("calc.zig:472-487 shading an intersection", [] {
         const World w = defaultWorld();

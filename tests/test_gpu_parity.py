@@ -575,6 +575,38 @@ def test_synthetic_scene_small_and_full_shape_count():
     assert st.radiance_rays == so.radiance_rays and st.sphere_hits == so.sphere_hits
 
 
+def test_synthetic_scene_at_3840x2160_sampled_rows():
+    """The 10 000-shape frame at the size its timing is quoted for, 3840x2160: twelve rows spread over the canvas
+    (46 080 pixels, every one through four levels of conservative single-precision pre-tests and per-lane work
+    lists) against the STREAMING oracle, value for value - the list walk and the hierarchy - and the weighted
+    integrator at its own bar (1e-9, 8-bit values within 1 LSB on at most 0.01 % of the channels).  What the
+    pre-tests may never change is calc.intersectWorld's result (calc.zig:200-214)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from raytracer_challenge_amd import byte_color_values
+
+    w, c = scenes.synthetic_scene(3840, 2160)
+    cd = c.desc()
+    rows = list(range(90, 2160, 180))
+    assert len(rows) == 12
+    # the oracle's rows in parallel (ctypes releases the interpreter lock; about two seconds of one core per row)
+    with ThreadPoolExecutor(max_workers=min(12, os.cpu_count() or 1)) as pool:
+        cpu = list(pool.map(lambda y: O.render_pixels(w, c, y * 3840 + np.arange(3840, dtype=np.uint64), 5, O.STREAMING), rows))
+    want = np.stack(cpu)  # (12, 3840, 3)
+    with scene_of(w) as sc:
+        walk = sc.render(cd, 5)[rows]
+        assert_identical(walk, want, "10 000 shapes at 3840x2160, list walk")
+        sc.set_acceleration(D.RTC_ACCEL_BVH)
+        assert_identical(sc.render(cd, 5)[rows], want, "10 000 shapes at 3840x2160, hierarchy")
+        sc.set_acceleration(D.RTC_ACCEL_NONE)
+        sc.set_integrator(D.RTC_INTEGRATOR_WEIGHTED)
+        weighted = sc.render(cd, 5)[rows]
+    delta = np.max(np.abs(weighted - want))
+    assert delta <= 1e-9, f"weighted integrator: max |delta| {delta:.3e}"
+    d = np.abs(byte_color_values(weighted).astype(np.int32) - byte_color_values(want).astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() <= 1e-4
+
+
 # ------------------------------------------------------------------------------- the cube (extension)
 def test_cubes_against_the_oracle():
     """RTC_GEO_CUBE, the primitive added through the shape-kind table beyond the reference's sphere and
