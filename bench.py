@@ -522,6 +522,15 @@ def main():
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max, kernel_ms_max, elapsed_u8_max, elapsed_peer_max, elapsed_host_max = (float(v) for v in t.tolist())
+    # how even the shares are: every rank's own kernel time and ray count (an uneven partition shows here)
+    mine = torch.tensor([kernel_ms, float(st.radiance_rays)], dtype=torch.float64,
+                        device="cpu" if (world_size > 1 and args.rehearse_on_one_gpu) else dev)
+    per_rank = [mine]
+    if world_size > 1:
+        per_rank = [torch.empty_like(mine) for _ in range(world_size)]
+        dist.all_gather(per_rank, mine)
+    rank_kernel_ms = [float(v[0]) for v in per_rank]
+    rank_rays = [int(v[1]) for v in per_rank]
 
     # Every N > 1 run checks what it assembled: rank 0 renders the whole frame alone (outside the timed
     # regions) and compares the canvases value for value.  A leg that differs is not reported.
@@ -586,6 +595,9 @@ def main():
             "traffic": (pmc["read_bytes"] + pmc["write_bytes"]) if pmc else None,
             "kernel": "render_kernel",
             "kernel_ms": kernel_ms,
+            # (with several ranks the headline may be the peer-store leg; the launches timed here are always these)
+            "kernel_ms_measured_on": "rank 0's launches of rtc_render_device into its " +
+            ("row-major canvas" if world_size == 1 else "dense tile buffer (the gather leg)"),
             "executed_flops_per_launch": local_executed,
             "algorithmic_flops_per_launch": local_flops,
             "achieved_algorithmic": achieved_alg,
@@ -695,6 +707,9 @@ def main():
                 "sweep": "hierarchy over the spheres (optional mode; flop figures below assume the list walk)"
                 if args.accel else "every shape against every ray (calc.zig:204-209)",
                 "render_kernel_ms_max_over_ranks": kernel_ms_max,
+                "render_kernel_ms_per_rank": {"min": min(rank_kernel_ms), "mean": sum(rank_kernel_ms) / len(rank_kernel_ms),
+                                              "max": max(rank_kernel_ms)},
+                "radiance_rays_per_rank": {"min": min(rank_rays), "max": max(rank_rays)},
             },
             "roofline": roofline,
         }
