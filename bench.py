@@ -122,8 +122,8 @@ def single_process_multi(native, D, world, cam, args, hsize, vsize):
     with native.Scene(world.shape_descs(), len(world.objects), world.light_desc()) as sc:
         want = sc.render(cam, args.depth)
     with native.Multi(world.shape_descs(), len(world.objects), world.light_desc(), args.multi_ranks) as m:
-        for name, mode in (("peer_stores", D.RTC_MULTI_PEER_STORES), ("peer_scatter", D.RTC_MULTI_PEER_SCATTER),
-                           ("rccl_gather", D.RTC_MULTI_RCCL_GATHER)):
+        for name, mode in (("peer_stores", D.RTC_MULTI_PEER_STORES), ("peer_block_stores", D.RTC_MULTI_PEER_BLOCK_STORES),
+                           ("peer_scatter", D.RTC_MULTI_PEER_SCATTER), ("rccl_gather", D.RTC_MULTI_RCCL_GATHER)):
             try:
                 same = bool(np.array_equal(m.render(cam, args.depth, mode), want))
                 for _ in range(args.warmup):
@@ -258,6 +258,9 @@ def main():
                     help="what every timed leg renders with: the reference's order of summation (default: the canvas is "
                     "value-identical to the reference's) or the attenuation-weighted sum (same rays; colours within a few "
                     "1e-16, canvases then compared at 1e-9 instead of exactly; no in-place peer stores)")
+    ap.add_argument("--canvas-store", default="pixels", choices=["pixels", "blocks"],
+                    help="rtc_scene_set_canvas_store for the headline leg: every finished pixel stored at once (default) "
+                    "or whole 8x8 blocks (meant for a canvas in a peer GPU's memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     # developer switches to rehearse the N > 1 path on a box with one GPU: every rank uses GPU 0
@@ -304,6 +307,8 @@ def main():
         world, camera = scenes.synthetic_scene(hsize, vsize)
     cam = camera.desc()
     scene = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
+    if args.canvas_store == "blocks":
+        scene.set_canvas_store(D.RTC_CANVAS_STORE_BLOCKS)
     if args.accel:
         scene.set_acceleration(D.RTC_ACCEL_BVH)
     weighted = args.integrator == "weighted"
@@ -482,8 +487,24 @@ def main():
         fence()
         elapsed_u8 = time.perf_counter() - t0
 
-    elapsed_peer = 0.0
+    elapsed_peer = elapsed_peer_blocks = 0.0
+    peer_blocks_copy = None
     if world_size > 1 and peer_canvas_usable:
+        # the same leg with the kernels' stores a finished 8x8 block at a time (192-byte runs over the link), first:
+        # its canvas is kept for the comparison below, then the per-pixel stores overwrite it
+        scene.set_canvas_store(D.RTC_CANVAS_STORE_BLOCKS)
+        for _ in range(max(args.warmup, 1)):
+            render_into_peer_canvas()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            render_into_peer_canvas()
+        fence()
+        elapsed_peer_blocks = time.perf_counter() - t0
+        if rank == 0:
+            peer_blocks_copy = _device_view(torch, peer_canvas, hsize * vsize * 3, dev).clone()
+        scene.set_canvas_store(D.RTC_CANVAS_STORE_PIXELS)
+        fence()
         for _ in range(max(args.warmup, 1)):
             render_into_peer_canvas()
         fence()
@@ -513,7 +534,7 @@ def main():
         step()
         fence()
 
-    t = torch.tensor([elapsed, kernel_ms, elapsed_u8, elapsed_peer, elapsed_host], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms, elapsed_u8, elapsed_peer, elapsed_host, elapsed_peer_blocks], dtype=torch.float64, device=dev)
     if world_size > 1:
         if args.rehearse_on_one_gpu:
             tc = t.cpu()
@@ -521,7 +542,7 @@ def main():
             t = tc
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max, kernel_ms_max, elapsed_u8_max, elapsed_peer_max, elapsed_host_max = (float(v) for v in t.tolist())
+    elapsed_max, kernel_ms_max, elapsed_u8_max, elapsed_peer_max, elapsed_host_max, elapsed_peer_blocks_max = (float(v) for v in t.tolist())
     # how even the shares are: every rank's own kernel time and ray count (an uneven partition shows here)
     mine = torch.tensor([kernel_ms, float(st.radiance_rays)], dtype=torch.float64,
                         device="cpu" if (world_size > 1 and args.rehearse_on_one_gpu) else dev)
@@ -534,7 +555,7 @@ def main():
 
     # Every N > 1 run checks what it assembled: rank 0 renders the whole frame alone (outside the timed
     # regions) and compares the canvases value for value.  A leg that differs is not reported.
-    gather_ok = peer_ok = host_ok = None
+    gather_ok = peer_ok = host_ok = peer_blocks_ok = None
     if world_size > 1 and rank == 0:
         whole = torch.empty(hsize * vsize * 3, dtype=torch.float64, device=dev)
         scene.render_device(cam, args.depth, whole.data_ptr(), 0, 1, stream)
@@ -545,6 +566,7 @@ def main():
         if peer_canvas_usable:
             peer_t = _device_view(torch, peer_canvas, hsize * vsize * 3, dev)
             peer_ok = bool(torch.equal(whole, peer_t))
+            peer_blocks_ok = bool(torch.equal(whole, peer_blocks_copy)) if peer_blocks_copy is not None else None
 
     if world_size > 1 and rank == 0:
         q = torch.empty(hsize * vsize * 3, dtype=torch.uint8, device=dev)
@@ -556,7 +578,7 @@ def main():
         else:
             u8_ok = bool(torch.equal(q, canvas_u8))
         if args.verify:
-            if not (gather_ok and u8_ok and peer_ok is not False and host_ok is not False):
+            if not (gather_ok and u8_ok and peer_ok is not False and host_ok is not False and peer_blocks_ok is not False):
                 raise SystemExit(f"verify FAILED: gather {gather_ok}, 8-bit gather {u8_ok}, peer stores {peer_ok}, "
                                  f"own D2H {host_ok}")
             print(f"verify ok: assembled canvases identical to the 1-rank render (f64 gather, 8-bit gather, "
@@ -571,9 +593,13 @@ def main():
             if not gather_ok:
                 raise SystemExit("the gathered canvas differs from the 1-rank render: no number is reported")
             # the headline is the faster of the two verified ways to the same f64 canvas on rank 0
-            if ms_peer is not None and ms_peer < ms_gather:
+            ms_peer_blocks = elapsed_peer_blocks_max * 1e3 / args.steps if (peer_canvas_usable and peer_blocks_ok) else None
+            if ms_peer is not None and ms_peer < ms_per_step:
                 ms_per_step = ms_peer
                 headline_leg = "peer stores into rank 0's canvas (HIP IPC mapping, no gather)"
+            if ms_peer_blocks is not None and ms_peer_blocks < ms_per_step:
+                ms_per_step = ms_peer_blocks
+                headline_leg = "peer stores into rank 0's canvas, a finished 8x8 block at a time (HIP IPC mapping, no gather)"
         rays_per_s = total["radiance_rays"] / (ms_per_step * 1e-3)
         # roofline of the dominant kernel (render_kernel) on THIS rank: algorithmic flops of
         # one launch / average launch duration from the HIP events above
@@ -706,6 +732,7 @@ def main():
                 "frame_ms": ms_per_step,
                 "sweep": "hierarchy over the spheres (optional mode; flop figures below assume the list walk)"
                 if args.accel else "every shape against every ray (calc.zig:204-209)",
+                "canvas_store": args.canvas_store,
                 "render_kernel_ms_max_over_ranks": kernel_ms_max,
                 "render_kernel_ms_per_rank": {"min": min(rank_kernel_ms), "mean": sum(rank_kernel_ms) / len(rank_kernel_ms),
                                               "max": max(rank_kernel_ms)},
@@ -725,6 +752,7 @@ def main():
             out["config"]["frame_ms_with_u8_gather"] = ms_u8 if u8_ok else None
             out["config"]["rays_per_s_with_u8_gather"] = total["radiance_rays"] / (ms_u8 * 1e-3) if u8_ok else None
             out["config"]["frame_ms_with_peer_stores"] = ms_peer
+            out["config"]["frame_ms_with_peer_block_stores"] = ms_peer_blocks
             out["config"]["peer_stores_unavailable_because"] = peer_why
             # every GPU copying its own tiles to pinned host memory, no gather (never the headline: the other legs
             # leave the canvas on rank 0's GPU, this one ends in N host buffers and includes the trip over PCIe)
@@ -732,7 +760,8 @@ def main():
                 elapsed_host_max * 1e3 / args.steps if (local_host is not None and host_ok) else None)
             out["config"]["own_d2h_unavailable_because"] = host_why
             out["config"]["canvases_verified_against_1_rank_render"] = {"f64_gather": gather_ok, "u8_gather": u8_ok,
-                                                                        "peer_stores": peer_ok, "own_d2h": host_ok}
+                                                                        "peer_stores": peer_ok, "own_d2h": host_ok,
+                                                                        "peer_block_stores": peer_blocks_ok}
         if world_size == 1 and not args.accel and not weighted:
             out["config"]["weighted_integrator"] = weighted_integrator_leg(torch, native, D, scene, cam, args, local, stream,
                                                                            total["radiance_rays"])

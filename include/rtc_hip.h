@@ -268,6 +268,20 @@ int rtc_render_device_noalloc(RtcScene* scene, const RtcCameraDesc* camera, int3
                               uint32_t tile_rank, uint32_t tile_ranks, void* d_out_rgb,
                               void* hip_stream, RtcStats* stats);
 
+/* How the render kernel stores finished pixels into a row-major canvas (rtc_render_device with tile_ranks == 1,
+ * rtc_render_device_to_canvas, rtc_render_device_noalloc; post-order integrator, calls without statistics).  No
+ * counterpart in the reference (canvas.zig:24-28 is one store per pixel on one thread).
+ *   RTC_CANVAS_STORE_PIXELS  (default) every lane stores its pixel's 24 bytes when the pixel is finished
+ *   RTC_CANVAS_STORE_BLOCKS  the finished pixels of an 8x8 block wait in a staging area of the wave that traces the
+ *                            block and are copied out together when the block is complete: eight runs of 192
+ *                            contiguous bytes per store instruction instead of scattered 24-byte stores.  Meant for a
+ *                            canvas in ANOTHER GPU's memory (peer access, IPC mapping), where small stores cross the
+ *                            link one by one.  Allocates the staging area (about 50 MB) when first selected.
+ * The canvas values are the same in both modes. */
+#define RTC_CANVAS_STORE_PIXELS 0
+#define RTC_CANVAS_STORE_BLOCKS 1
+int rtc_scene_set_canvas_store(RtcScene* scene, int32_t mode);
+
 /* rtc_render_device with the rank's pixels stored at their final place: d_canvas_rgb is the full
  * row-major canvas (hsize*vsize*3 doubles) and this call fills the pixels of the tiles t with
  * t % tile_ranks == tile_rank, leaving the others untouched.  The canvas may live in another GPU's
@@ -360,6 +374,10 @@ int rtc_multi_set_integrator(RtcMulti* multi, int32_t integrator);
                                     rendered and copied as by rtc_render.  In RtcMultiTiming the transfer to
                                     the pinned canvas counts as render_and_transfer_ms, the host threads'
                                     copy as to_host_ms */
+#define RTC_MULTI_PEER_BLOCK_STORES 4 /* RTC_MULTI_PEER_STORES with the render kernels' stores switched to whole
+                                         8x8 blocks (rtc_scene_set_canvas_store: RTC_CANVAS_STORE_BLOCKS): what
+                                         crosses the link are runs of 192 contiguous bytes instead of single
+                                         pixels of 24 */
 
 /* Device-side phases of one call, in milliseconds: from the first launch until every rank's pixels
  * are on rank 0's GPU (rendering and the transfers, which overlap in the peer modes), then rank

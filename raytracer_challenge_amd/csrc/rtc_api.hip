@@ -229,6 +229,9 @@ struct RtcScene {
     int32_t bvh_root = 0;
     double bvh_origin_limit = 0;
     int32_t integrator = RTC_INTEGRATOR_POSTORDER;  // rtc_scene_set_integrator
+    int32_t canvas_store = RTC_CANVAS_STORE_PIXELS;  // rtc_scene_set_canvas_store
+    double* d_flush_stage = nullptr;                 // staging area of the block stores (see DevJob::flush_stage)
+    uint32_t flush_waves = 0;
     void* h_staging = nullptr;  // pinned staging buffer of rtc_render's copy to the host, kept between calls
     size_t staging_bytes = 0;
     std::vector<hipEvent_t> slice_events;
@@ -257,6 +260,7 @@ void free_scene(RtcScene* s) {
     if (s->h_staging) (void)hipHostFree(s->h_staging);
     for (hipEvent_t ev : s->slice_events) (void)hipEventDestroy(ev);
     if (s->d_bvh) (void)hipFree(s->d_bvh);
+    if (s->d_flush_stage) (void)hipFree(s->d_flush_stage);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
     delete s;
@@ -928,6 +932,11 @@ int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, 
         return fail(RTC_ERR_INVALID_ARGUMENT, buf);
     }
     job.weighted = s->integrator == RTC_INTEGRATOR_WEIGHTED ? 1 : 0;
+    // block stores: canvases in row-major layout, post-order integrator, frame kernels (see launch_tables)
+    const bool block_stores = s->canvas_store == RTC_CANVAS_STORE_BLOCKS && job.out_row_major && !job.weighted && !stats &&
+                              job.rays == nullptr && s->d_flush_stage != nullptr;
+    job.flush_stage = block_stores ? s->d_flush_stage : nullptr;
+    job.flush_waves = block_stores ? s->flush_waves : 0u;
     if (job.weighted && job.out_row_major && job.tile_ranks > 1)
         return fail(RTC_ERR_INVALID_ARGUMENT,
                     "the weighted integrator adds to its output with atomics and renders a partition into its own tile "
@@ -1491,6 +1500,26 @@ int rtc_scene_set_integrator(RtcScene* scene, int32_t integrator) {
     if (integrator != RTC_INTEGRATOR_POSTORDER && integrator != RTC_INTEGRATOR_WEIGHTED)
         return fail(RTC_ERR_INVALID_ARGUMENT, "unknown integrator");
     scene->integrator = integrator;
+    return RTC_OK;
+}
+
+int rtc_scene_set_canvas_store(RtcScene* scene, int32_t mode) {
+    if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
+    if (mode != RTC_CANVAS_STORE_PIXELS && mode != RTC_CANVAS_STORE_BLOCKS)
+        return fail(RTC_ERR_INVALID_ARGUMENT, "unknown canvas store mode");
+    if (mode == RTC_CANVAS_STORE_BLOCKS && !scene->d_flush_stage) {
+        // the staging area, allocated here (set-up time) for as many waves as the GPU can hold at once: four slots of
+        // one 8x8 block of f64 RGB per wave
+        int dev = 0, cus = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev != scene->device) return fail(RTC_ERR_INVALID_ARGUMENT, "the scene's device must be the current one");
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const uint32_t waves = (uint32_t)cus * 32u;  // 2048 threads per CU at most
+        const size_t bytes = (size_t)waves * rtc::kFlushSlots * 64 * 3 * sizeof(double);
+        HIP_TRY(hipMalloc((void**)&scene->d_flush_stage, bytes));
+        scene->flush_waves = waves;
+    }
+    scene->canvas_store = mode;
     return RTC_OK;
 }
 

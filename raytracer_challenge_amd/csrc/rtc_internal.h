@@ -46,6 +46,7 @@ constexpr int kSphereBoundsPadding = 80;  // entries the streamed sweep may read
 constexpr int kLdsShapeLimit = RTC_LDS_SHAPES;  // worlds of at most this many shapes keep their per-hit tables in LDS
 constexpr int kSphereBlock = 8;           // spheres per block of the streamed sweep's block test
 constexpr int kRecordDoubles = 24;  // doubles per sweep-table record (see DevWorld)
+constexpr int kFlushSlots = 4;      // blocks per wave whose finished pixels can wait in the staging area (block stores)
 
 // The sweep table is grouped by kind of test: one row per group, in table order.  A shape kind
 // (Shape.geo, shape.zig:76-79) owns one or more groups; a group is swept by a loop specialised for
@@ -182,6 +183,10 @@ struct DevJob {
     int32_t depth;
     int32_t weighted;  // 1: the attenuation-weighted integrator (render_weighted_kernel) instead of the post-order one
     double* out;
+    // block stores (rtc_scene_set_canvas_store): the waves' staging area, kFlushSlots x 64 pixels x 3 doubles for each
+    // of the first flush_waves waves of the grid, or nullptr = every pixel is stored when it is finished
+    double* flush_stage;
+    uint32_t flush_waves, flush_pad;
     uint32_t* counter;  // control block: the work-queue heads first, zeroed before the launch
     uint64_t* stats;    // 9 counters (radiance, shadow, sphere hits, plane hits, shaded, sphere skips, plane skips, cube hits, prefilter skips) or nullptr
 };

@@ -1312,12 +1312,29 @@ __device__ __forceinline__ WorldArg world_argument() {
     return w;
 }
 
+// Block stores (rtc_scene_set_canvas_store: RTC_CANVAS_STORE_BLOCKS).  A lane that finishes a pixel normally stores its
+// 24 bytes at once, alone or with the few lanes that finish in the same iteration: fine for local memory, whose L2
+// merges them, but a poor transaction size when the canvas is another GPU's memory.  Every pixel of an 8x8 block is
+// traced by lanes of the ONE wave that drew the block, so that wave can tell when the block is complete without any
+// synchronisation: it parks finished colours in a staging area of its own (global memory; kFlushSlots blocks in
+// flight per wave, a block that finds no free slot falls back to per-pixel stores) and, when the last pixel of a
+// block is done, copies the block out with all 64 lanes in one go: eight runs of 192 contiguous bytes.
+constexpr uint32_t kOutStaged = 0x80000000u;  // out_pixel holds (slot << 6 | position in the block), not a canvas index
+template <bool ON>
+struct FlushTable {};
+template <>
+struct FlushTable<true> {
+    int left[kBlock / 64][kFlushSlots];
+    uint32_t out0[kBlock / 64][kFlushSlots], nx[kBlock / 64][kFlushSlots], ny[kBlock / 64][kFlushSlots];
+};
+
 // The read-only tables and the output are separate __restrict__ kernel arguments so that
 // the compiler can prove the wave-uniform table reads are never clobbered by the kernel's
 // own stores and keep them on the scalar path; the structs carry the remaining scalars.
 // TABLES: 3 = as 1, for worlds without cubes and general spheres (launch_variant); 0 = per-hit tables gathered from global memory, 1 = from their LDS copy (small
 // worlds), 2 = global memory and the spheres swept through the hierarchy.
-template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
+// FLUSH: the finished pixels of an 8x8 block are stored together when the block's last pixel is done (see kFlushSlots).
+template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES, bool FLUSH = false>
 __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_WAVES_PER_EU) void render_kernel(const double* __restrict__ g_tab,
                                                         const DevShade* __restrict__ g_shade,
                                                         const int* __restrict__ g_order,
@@ -1436,6 +1453,14 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     uint32_t blk_base = 0, blk_px0 = 0, blk_py0 = 0;
     bool blk_valid = false;
     uint32_t blk_out0 = 0;
+    // FLUSH: per wave and staging slot, in LDS (touched when a block is drawn or completed, so not worth registers):
+    // the pixels of the slot's block still in flight (0 = free), the canvas index of the block's first pixel and the
+    // block's extent inside the canvas; in a register the slot of the block being dealt (-1 = none), wave-uniform
+    __shared__ FlushTable<FLUSH> fl;
+    int blk_slot = -1;
+    if constexpr (FLUSH) {
+        if (lane < kFlushSlots) fl.left[threadIdx.x >> 6][lane] = 0;  // (read by the same wave only)
+    }
     // (job.cam_origin is inverse(camera.transform) * point(0,0,0) (camera.zig:60): the same value
     // for every pixel, evaluated once on the host with the same expression)
 
@@ -1476,12 +1501,15 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
         aux = job.depth << kAuxRemShift;  \
         sp = 0;                           \
     } while (0)
+#define RTC_REFILL_BLOCK_SLOTS
 #include "rtc_refill.inc"
+#undef RTC_REFILL_BLOCK_SLOTS
 #undef RTC_START_TASK
         const bool drained = exhausted && loc_next >= loc_end;  // wave-uniform: no pixel left to start
 
         bool have_ret = false;     // a finished subtree colour is in `ret`, to be unwound into the frames
         V3 ret = {0.0, 0.0, 0.0};  // Color.Black on a miss (calc.zig:650)
+        int fl_done = -1;          // FLUSH: the staging slot of the pixel this lane finished in this iteration
 
 #ifndef RTC_NO_STEAL
         // ---- queue empty: idle lanes take over parked refracted subtrees -------------------
@@ -1664,15 +1692,54 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
 #ifdef RTC_COSTMAP
                     ret = {(double)cost_nodes, 0.0, 0.0};  // developer build: nodes traced per pixel instead of the colour
 #endif
-                    double* __restrict__ px_out = g_out + (size_t)out_pixel * 3;
-                    px_out[0] = ret.x;
-                    px_out[1] = ret.y;
-                    px_out[2] = ret.z;
+                    if (FLUSH && (out_pixel & kOutStaged)) {
+                        // parked in the wave's staging area until its block is complete (plain stores: the vector L1 is
+                        // write-through, so they land in the L2, where the copy-out below reads them past the L1,
+                        // whichever lane does; the slot is reused at once and mostly never leaves the L2)
+                        const uint32_t fl_wave = (blockIdx.x * (kBlock / 64)) + (threadIdx.x >> 6);
+                        double* st = job.flush_stage + ((size_t)fl_wave * (kFlushSlots * 64) + (out_pixel & 0xffu)) * 3;
+                        st[0] = ret.x;
+                        st[1] = ret.y;
+                        st[2] = ret.z;
+                        fl_done = (int)((out_pixel >> 6) & 3u);
+                    } else {
+                        double* __restrict__ px_out = g_out + (size_t)out_pixel * 3;
+                        px_out[0] = ret.x;
+                        px_out[1] = ret.y;
+                        px_out[2] = ret.z;
+                    }
                     mode = kIdle;
                 }
             }
         }
         RTC_STAMP(pc_unwind);
+        if constexpr (FLUSH) {
+            // blocks completed by this iteration's pixels leave the staging area: lane i copies pixel i of the block
+            if (__ballot(fl_done >= 0) != 0) {
+                const int wv = (int)(threadIdx.x >> 6);
+                const uint32_t fl_wave = (blockIdx.x * (kBlock / 64)) + (threadIdx.x >> 6);
+#pragma unroll 1
+                for (int k = 0; k < kFlushSlots; ++k) {
+                    const unsigned long long m = __ballot(fl_done == k);
+                    if (m == 0) continue;
+                    const int left = fl.left[wv][k] - __popcll(m);  // (every lane computes and writes the same value)
+                    fl.left[wv][k] = left;
+                    if (left > 0) continue;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the wave's staged stores are complete
+                    const uint32_t x = (uint32_t)lane & 7u, y = (uint32_t)lane >> 3;
+                    if (x < fl.nx[wv][k] && y < fl.ny[wv][k]) {
+                        const double* st = job.flush_stage + ((size_t)fl_wave * (kFlushSlots * 64) + (size_t)(k * 64 + lane)) * 3;
+                        const double r = __hip_atomic_load(st + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const double g = __hip_atomic_load(st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const double b = __hip_atomic_load(st + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        double* __restrict__ px_out = g_out + ((size_t)fl.out0[wv][k] + (size_t)y * job.hsize + x) * 3;
+                        px_out[0] = r;
+                        px_out[1] = g;
+                        px_out[2] = b;
+                    }
+                }
+            }
+        }
     }
 
 #ifdef RTC_PROBE
@@ -2031,6 +2098,10 @@ __global__ __launch_bounds__(kBlock) void arith_probe_kernel(const double* __res
 template <int MAXD, bool STATS, bool FROM_RAYS, int TABLES>
 hipError_t launch_tables(const DevWorld& world, const DevJob& job, hipStream_t stream) {
     auto kernel = job.weighted ? render_weighted_kernel<MAXD, STATS, FROM_RAYS, TABLES> : render_kernel<MAXD, STATS, FROM_RAYS, TABLES>;
+    // block stores: frame kernels of the post-order integrator only (no statistics, camera rays)
+    if constexpr (!STATS && !FROM_RAYS) {
+        if (!job.weighted && job.flush_stage != nullptr && job.out_row_major) kernel = render_kernel<MAXD, STATS, FROM_RAYS, TABLES, true>;
+    }
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

@@ -8,6 +8,7 @@
 //   RTC_MULTI_PEER_STORES   the render kernels store every finished pixel at its final place in
 //                           rank 0's canvas through peer access (xGMI): no tile buffers, no gather,
 //                           no de-interleave pass; the transfers hide under the rendering
+//   RTC_MULTI_PEER_BLOCK_STORES  the same, a finished 8x8 block at a time (192-byte runs instead of 24-byte stores)
 //   RTC_MULTI_PEER_SCATTER  each rank renders into a dense tile buffer in its own HBM, (quantises it,
 //                           for the 8-bit canvas), and a scatter kernel on that rank writes the
 //                           tiles into rank 0's canvas through peer access in long runs
@@ -211,8 +212,11 @@ uint64_t doubles_of_rank(const RtcCameraDesc* cam, uint32_t rank, uint32_t ranks
 int render_frame(RtcMulti* m, const RtcCameraDesc* cam, int32_t depth, int32_t mode, bool want_u8, RtcStats* stats) {
     const uint32_t R = m->ranks;
     if (mode != RTC_MULTI_PEER_STORES && mode != RTC_MULTI_PEER_SCATTER && mode != RTC_MULTI_RCCL_GATHER &&
-        mode != RTC_MULTI_HOST_DIRECT)
+        mode != RTC_MULTI_HOST_DIRECT && mode != RTC_MULTI_PEER_BLOCK_STORES)
         return rtc::set_error(RTC_ERR_INVALID_ARGUMENT, "unknown multi-GPU mode");
+    // peer stores a block at a time: the same path with the kernels' canvas stores switched to whole 8x8 blocks
+    const int32_t canvas_store = mode == RTC_MULTI_PEER_BLOCK_STORES ? RTC_CANVAS_STORE_BLOCKS : RTC_CANVAS_STORE_PIXELS;
+    if (mode == RTC_MULTI_PEER_BLOCK_STORES) mode = RTC_MULTI_PEER_STORES;
     // one rank: the canvas is rendered where rtc_render renders it, and copied like there
     const bool host_direct = mode == RTC_MULTI_HOST_DIRECT && R > 1;
     if (mode == RTC_MULTI_HOST_DIRECT && R == 1) mode = RTC_MULTI_PEER_STORES;
@@ -314,6 +318,7 @@ int render_frame(RtcMulti* m, const RtcCameraDesc* cam, int32_t depth, int32_t m
         MULTI_HIP(hipSetDevice(m->device[r]));
         RtcStats s{};
         RtcStats* sp = stats ? &s : nullptr;
+        MULTI_RTC(rtc_scene_set_canvas_store(m->scene[r], canvas_store));  // (allocates its staging area once)
         if (R == 1) {
             MULTI_RTC(rtc_render_device(m->scene[r], cam, depth, 0, 1, m->canvas, m->stream[r], sp));
         } else if (!tiled) {

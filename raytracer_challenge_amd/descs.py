@@ -29,6 +29,8 @@ RTC_ACCEL_NONE = 0
 RTC_ACCEL_BVH = 1
 RTC_INTEGRATOR_POSTORDER = 0
 RTC_INTEGRATOR_WEIGHTED = 1
+RTC_CANVAS_STORE_PIXELS = 0
+RTC_CANVAS_STORE_BLOCKS = 1
 RTC_NOALLOC_MAX_TILES = 262144
 RTC_MULTI_MAX_RANKS = 64
 RTC_IPC_HANDLE_BYTES = 64
@@ -36,6 +38,7 @@ RTC_MULTI_PEER_STORES = 0
 RTC_MULTI_PEER_SCATTER = 1
 RTC_MULTI_RCCL_GATHER = 2
 RTC_MULTI_HOST_DIRECT = 3
+RTC_MULTI_PEER_BLOCK_STORES = 4
 RTC_TILE_W = 64
 RTC_TILE_H = 8
 

@@ -47,6 +47,7 @@ def lib():
     L.rtc_scene_destroy.argtypes = [vp]
     L.rtc_scene_set_acceleration.argtypes = [vp, i32]
     L.rtc_scene_set_integrator.argtypes = [vp, i32]
+    L.rtc_scene_set_canvas_store.argtypes = [vp, i32]
     L.rtc_scene_group_counts.argtypes = [vp, C.POINTER(C.c_uint64 * D.RTC_SWEEP_GROUPS)]
     L.rtc_sweep_group_info.argtypes = [u32, C.POINTER(D.RtcSweepGroupInfo)]
     L.rtc_render.argtypes = [vp, C.POINTER(D.RtcCameraDesc), i32, dp, C.POINTER(D.RtcStats)]
@@ -91,6 +92,7 @@ EXPORTS = (
     "rtc_scene_destroy",
     "rtc_scene_set_acceleration",
     "rtc_scene_set_integrator",
+    "rtc_scene_set_canvas_store",
     "rtc_scene_group_counts",
     "rtc_sweep_group_info",
     "rtc_render",
@@ -238,6 +240,10 @@ class Scene:
     def set_integrator(self, integrator):
         """rtc_scene_set_integrator: 0 = the reference's post-order sum (default), 1 = attenuation-weighted."""
         check(lib().rtc_scene_set_integrator(self._h, int(integrator)))
+
+    def set_canvas_store(self, mode):
+        """rtc_scene_set_canvas_store: 0 = every finished pixel stored at once (default), 1 = whole 8x8 blocks."""
+        check(lib().rtc_scene_set_canvas_store(self._h, int(mode)))
 
     def set_acceleration(self, mode):
         """rtc_scene_set_acceleration: 0 = test every shape (default), 1 = hierarchy over the spheres."""

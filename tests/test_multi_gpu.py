@@ -14,7 +14,8 @@ from raytracer_challenge_amd import byte_color_values, descs as D, native, scene
 
 pytestmark = pytest.mark.gpu
 
-MODES = (D.RTC_MULTI_PEER_STORES, D.RTC_MULTI_PEER_SCATTER, D.RTC_MULTI_RCCL_GATHER, D.RTC_MULTI_HOST_DIRECT)
+MODES = (D.RTC_MULTI_PEER_STORES, D.RTC_MULTI_PEER_BLOCK_STORES, D.RTC_MULTI_PEER_SCATTER, D.RTC_MULTI_RCCL_GATHER,
+         D.RTC_MULTI_HOST_DIRECT)
 
 
 def _multi(world, ranks, devices=None):
@@ -165,4 +166,47 @@ def test_one_process_per_rank_front_end_with_ipc_canvas():
     out = json.loads(line)
     assert out["n_gpus"] == 2
     assert out["config"]["canvases_verified_against_1_rank_render"] == {"f64_gather": True, "u8_gather": True,
-                                                                        "peer_stores": True, "own_d2h": True}
+                                                                        "peer_stores": True, "own_d2h": True,
+                                                                        "peer_block_stores": True}
+
+
+def test_block_stores_give_the_same_canvas():
+    """rtc_scene_set_canvas_store(RTC_CANVAS_STORE_BLOCKS): the finished pixels of an 8x8 block leave the wave's
+    staging area together (runs of 192 bytes for a canvas in a peer GPU's memory).  Same values as per-pixel
+    stores: whole frames (ragged sizes, one pixel, deep recursion), ranks storing into one shared canvas, the
+    entry point that allocates nothing, and back again."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    w, _ = scenes.draw_world_scene(64, 32)
+    with native.Scene(w.shape_descs(), len(w.objects), w.light_desc()) as sc:
+        for size, depth in (((333, 97), 5), ((1, 1), 5), ((7, 300), 5), ((640, 360), 5), ((200, 100), 11), ((1920, 1080), 5)):
+            cd = scenes.draw_world_scene(*size)[1].desc()
+            n = cd.hsize * cd.vsize * 3
+            want = torch.full((n,), -7.0, dtype=torch.float64, device=dev)
+            sc.set_canvas_store(D.RTC_CANVAS_STORE_PIXELS)
+            sc.render_device(cd, depth, want.data_ptr())
+            torch.cuda.synchronize()
+            sc.set_canvas_store(D.RTC_CANVAS_STORE_BLOCKS)
+            got = torch.full((n,), -7.0, dtype=torch.float64, device=dev)
+            sc.render_device(cd, depth, got.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), f"{size} depth {depth}, whole frame"
+            # three ranks into one canvas, one after the other (they share the scene's staging area)
+            got.fill_(-7.0)
+            for r in range(3):
+                sc.render_device_to_canvas(cd, depth, got.data_ptr(), r, 3)
+                torch.cuda.synchronize()
+            assert torch.equal(got, want), f"{size} depth {depth}, three ranks in place"
+            got.fill_(-7.0)
+            sc.render_device_noalloc(cd, depth, got.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), f"{size} depth {depth}, no-alloc entry point"
+            # with statistics the per-pixel kernel runs whatever the mode
+            st = D.RtcStats()
+            got.fill_(-7.0)
+            sc.render_device(cd, depth, got.data_ptr(), 0, 1, None, st)
+            assert torch.equal(got, want) and st.pixels == cd.hsize * cd.vsize
+        sc.set_canvas_store(D.RTC_CANVAS_STORE_PIXELS)
+        with pytest.raises(native.RtcError):
+            sc.set_canvas_store(7)
