@@ -14,7 +14,8 @@ for ranks in (1, 2, 4, 8):
     n = native.tile_buffer_doubles(cd, 0, ranks)
     out = torch.empty(n, dtype=torch.float64, device="cuda")
     worst = 0.0
-    for r in range(ranks if ranks <= 2 else 2):
+    per_rank = []
+    for r in range(ranks if (ranks <= 2 or "--all-ranks" in sys.argv) else 2):
         for _ in range(3):
             sc.render_device(cd, 5, out.data_ptr(), r, ranks)
         torch.cuda.synchronize()
@@ -24,6 +25,8 @@ for ranks in (1, 2, 4, 8):
             a.record(); sc.render_device(cd, 5, out.data_ptr(), r, ranks); b.record(); torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
         worst = max(worst, sorted(ts)[len(ts) // 2])
+        per_rank.append(sorted(ts)[len(ts) // 2])
     if ranks == 1:
         full = worst
-    print(f"{wl} ranks {ranks}: render {worst:.3f} ms per rank; render-only efficiency {full / (ranks * worst):.2f}")
+    print(f"{wl} ranks {ranks}: render {worst:.3f} ms per rank; render-only efficiency {full / (ranks * worst):.2f}"
+          + (f"; every rank's share: {' '.join(f'{t:.3f}' for t in per_rank)} ms" if len(per_rank) > 2 else ""))
