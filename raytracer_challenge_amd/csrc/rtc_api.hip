@@ -239,7 +239,10 @@ struct RtcScene {
     size_t canvas_bytes = 0;
     uint32_t* d_tile_order = nullptr;
     uint64_t tile_order_capacity = 0;
-    bool plan_valid = false, plan_identity = true;
+    unsigned long long* d_strip_order = nullptr;  // the queue in strips (build_strip_order), when the plan has one
+    uint64_t strip_order_capacity = 0;
+    bool plan_valid = false, plan_identity = true, plan_has_strips = false, plan_row_major = false;
+    int plan_strips = 0;
     RtcCameraDesc plan_camera{};
     uint32_t plan_rank = 0, plan_ranks = 0;
 };
@@ -256,6 +259,7 @@ void free_scene(RtcScene* s) {
     if (s->d_shade) (void)hipFree(s->d_shade);
     if (s->d_counter) (void)hipFree(s->d_counter);
     if (s->d_tile_order) (void)hipFree(s->d_tile_order);
+    if (s->d_strip_order) (void)hipFree(s->d_strip_order);
     if (s->d_canvas) (void)hipFree(s->d_canvas);
     if (s->h_staging) (void)hipHostFree(s->h_staging);
     for (hipEvent_t ev : s->slice_events) (void)hipEventDestroy(ev);
@@ -562,9 +566,13 @@ double largest_stretch(const double* m) {
 // This only orders the work: every pixel is computed by the same arithmetic whatever its
 // place in the queue.  This function is the host arithmetic (queue slot -> local tile index);
 // `order` comes back empty when the natural order is kept.
+struct PixelBox {
+    double x0, x1, y0, y1;  // extent on the canvas, in pixels, of where a transparent shape can show
+};
 int compute_tile_order(const RtcScene* s, const RtcCameraDesc* cam, const rtc::DevJob* job, uint64_t local_tiles,
-                       std::vector<uint32_t>& order) {
+                       std::vector<uint32_t>& order, std::vector<PixelBox>* pixel_boxes = nullptr) {
     order.clear();
+    if (pixel_boxes) pixel_boxes->clear();
     if (local_tiles < 2 || s->costly_everywhere || s->costly.empty()) return RTC_OK;
     const uint32_t tiles_x = job->tiles_x, ranks = job->tile_ranks, rank = job->tile_rank;
     const uint32_t tiles_y = job->tiles_total / tiles_x;
@@ -598,6 +606,7 @@ int compute_tile_order(const RtcScene* s, const RtcCameraDesc* cam, const rtc::D
         const uint32_t ty1 = py1 < (double)cam->vsize ? (uint32_t)(py1 / RTC_TILE_H) : tiles_y - 1;
         for (uint32_t ty = ty0; ty <= ty1 && ty < tiles_y; ++ty) row_score[ty] += (uint64_t)(tx1 - tx0 + 1);
         boxes.push_back({tx0, tx1, ty0, ty1});
+        if (pixel_boxes) pixel_boxes->push_back({px0, px1, py0, py1});
         any = true;
     }
     if (!any) return RTC_OK;
@@ -651,30 +660,134 @@ int compute_tile_order(const RtcScene* s, const RtcCameraDesc* cam, const rtc::D
     return RTC_OK;
 }
 
+// The queue at a finer grain: strips of 8 x 2 pixels, four to a chunk of 64 queue positions (rtc_refill.inc).
+// A block of 64 pixels that all show a transparent shape keeps its wave for some 45 node iterations, with every lane
+// busy on a long chain of its own: on a share of a frame that the GPU finishes in little more than that, those waves
+// end long after the others.  Here such blocks are dealt a strip at a time, each together with three strips of an
+// ordinary block: a wave then holds 16 costly pixels and 48 cheap ones, the costly work is spread over four times as
+// many waves from the start, and once the queue is empty the lanes the cheap pixels leave idle take over the parked
+// subtrees of the costly ones.  Only the schedule changes: a pixel's arithmetic does not depend on its wave.
+// An entry: low word = (first pixel's x / 8) | (first pixel's y / 2) << 16, or 0xffffffff for a strip outside the
+// canvas; high word = index of the strip's first pixel in the output (canvas, or the rank's dense tile buffer).
+constexpr uint32_t kStripsPerTile = RTC_TILE_W * RTC_TILE_H / 16;
+bool strips_usable(const RtcCameraDesc* cam) { return cam->hsize < (1u << 19) && cam->vsize < (1u << 17); }
+void build_strip_order(const RtcCameraDesc* cam, const rtc::DevJob* job, uint64_t local_tiles, const std::vector<uint32_t>& tile_order,
+                       const std::vector<PixelBox>& boxes, int variant, std::vector<uint64_t>& strips) {
+    const uint32_t tiles_x = job->tiles_x, ranks = job->tile_ranks, rank = job->tile_rank;
+    const uint32_t hsize = (uint32_t)cam->hsize, vsize = (uint32_t)cam->vsize;
+    std::vector<uint64_t> costly, cheap, outside;
+    costly.reserve(local_tiles * 4);
+    cheap.reserve(local_tiles * kStripsPerTile);
+    for (uint64_t slot = 0; slot < local_tiles; ++slot) {
+        const uint64_t lt = tile_order.empty() ? slot : tile_order[slot];
+        const uint64_t gt = lt * ranks + rank;
+        const uint32_t tx0 = (uint32_t)(gt % tiles_x) * RTC_TILE_W, ty0 = (uint32_t)(gt / tiles_x) * RTC_TILE_H;
+        for (uint32_t blk = 0; blk < RTC_TILE_W / 8; ++blk) {
+            const uint32_t bx0 = tx0 + blk * 8;
+            // does the 8 x 8 block overlap the extent of a transparent shape?
+            bool marked = false;
+            for (const PixelBox& b : boxes)
+                marked = marked || (b.x1 >= (double)bx0 && b.x0 < (double)(bx0 + 8) && b.y1 >= (double)ty0 && b.y0 < (double)(ty0 + 8));
+            for (uint32_t rp = 0; rp < RTC_TILE_H / 2; ++rp) {
+                const uint32_t py0 = ty0 + rp * 2;
+                const uint64_t out0 = job->out_row_major ? (uint64_t)py0 * hsize + bx0
+                                                         : lt * (RTC_TILE_W * RTC_TILE_H) + (uint64_t)rp * 2 * RTC_TILE_W + blk * 8;
+                const bool inside = gt < job->tiles_total && bx0 < hsize && py0 < vsize;
+                const uint64_t entry = inside ? ((out0 << 32) | (uint64_t)((bx0 / 8) | ((py0 / 2) << 16))) : 0xffffffffull;
+                (inside ? (marked ? costly : cheap) : outside).push_back(entry);
+            }
+        }
+    }
+    strips.clear();
+    strips.reserve(local_tiles * kStripsPerTile);
+    size_t c = 0, p = 0;
+    // variant 1: one costly strip with three cheap ones while both last ...
+    while (variant == 1 && c < costly.size() && p + 3 <= cheap.size()) {
+        strips.push_back(costly[c++]);
+        strips.push_back(cheap[p++]);
+        strips.push_back(cheap[p++]);
+        strips.push_back(cheap[p++]);
+    }
+    // ... then what is left of either (whole blocks again, in the order above), and the strips outside the canvas last
+    while (c < costly.size()) strips.push_back(costly[c++]);
+    while (p < cheap.size()) strips.push_back(cheap[p++]);
+    for (uint64_t e : outside) strips.push_back(e);
+}
+
+// How the queue of this launch is dealt (build_strip_order): 0 = whole tiles in the order of compute_tile_order,
+// 1 = in strips, one strip of a costly block with three of an ordinary one, 2 = in strips, whole costly blocks first.
+// Measured on the Ch. 11 scene (scripts/partition_timing.py, blocks of the share per wave the GPU holds):
+//   up to 2 blocks per wave (1080p over 4 or 8 ranks)   1: 0.407 -> 0.387 ms, 0.357 -> 0.279 ms (2: 0.394 / 0.355)
+//   4 to 32 (4K over 1 to 8 ranks, 1080p)               2: 2.23 -> 2.17, 1.14 -> 1.10, 0.73 -> 0.68, 0.475 -> 0.449 ms
+//                                                          (1 mixes two kinds of pixel in every wave: 2.13 -> 2.69 ms)
+//   126 (7680x4320)                                      0: 7.42 ms against 7.62 ms with 2
+// RTC_STRIP_QUEUE=0/1/2 in the environment forces a variant (a developer switch for timing).
+int strip_queue_variant(const rtc::DevJob* job, uint64_t local_tiles) {
+    static const int forced = [] {
+        const char* e = std::getenv("RTC_STRIP_QUEUE");
+        return e && *e ? std::atoi(e) : -1;
+    }();
+    if (forced >= 0) return forced;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return 0;
+    (void)job;
+    const uint64_t resident_waves = (uint64_t)cus * 16, blocks = local_tiles * (RTC_TILE_W * RTC_TILE_H / 64);
+    if (blocks <= 2 * resident_waves) return 1;
+    if (blocks <= 48 * resident_waves) return 2;
+    return 0;
+}
+
 // The plan in the scene's own buffer (grown with hipMalloc when needed), cached per camera and partition.
 int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uint64_t local_tiles,
                     hipStream_t stream) {
     job->tile_order = nullptr;
+    job->strip_order = nullptr;
     if (local_tiles < 2 || s->costly_everywhere || s->costly.empty()) return RTC_OK;
-    if (s->plan_valid && s->plan_rank == job->tile_rank && s->plan_ranks == job->tile_ranks &&
-        std::memcmp(&s->plan_camera, cam, sizeof *cam) == 0) {
+    // (block stores need every pixel of a block in one wave: no strips then)
+    const int strips = (strips_usable(cam) && !(s->canvas_store == RTC_CANVAS_STORE_BLOCKS && job->out_row_major))
+                           ? strip_queue_variant(job, local_tiles)
+                           : 0;
+    if (s->plan_valid && s->plan_rank == job->tile_rank && s->plan_ranks == job->tile_ranks && s->plan_strips == strips &&
+        s->plan_row_major == (job->out_row_major != 0) && std::memcmp(&s->plan_camera, cam, sizeof *cam) == 0) {
         job->tile_order = s->plan_identity ? nullptr : s->d_tile_order;
+        job->strip_order = s->plan_has_strips ? s->d_strip_order : nullptr;
+        if (job->strip_order) job->tile_order = nullptr;
         return RTC_OK;
     }
     std::vector<uint32_t> order;
-    if (int rc = compute_tile_order(s, cam, job, local_tiles, order)) return rc;
+    std::vector<PixelBox> boxes;
+    if (int rc = compute_tile_order(s, cam, job, local_tiles, order, &boxes)) return rc;
+    std::vector<uint64_t> strip_table;
+    if (strips != 0 && !boxes.empty()) build_strip_order(cam, job, local_tiles, order, boxes, strips, strip_table);
     // the cache describes a plan only once that plan is on the device (or needs no upload)
     s->plan_valid = false;
     s->plan_camera = *cam;
     s->plan_rank = job->tile_rank;
     s->plan_ranks = job->tile_ranks;
+    s->plan_strips = strips;
+    s->plan_row_major = job->out_row_major != 0;
     s->plan_identity = order.empty();
-    if (order.empty()) {
+    s->plan_has_strips = !strip_table.empty();
+    if (order.empty() && strip_table.empty()) {
         s->plan_valid = true;
         return RTC_OK;
     }
     // an earlier launch on this stream may still be reading the previous plan
     HIP_TRY(hipStreamSynchronize(stream));
+    if (!strip_table.empty()) {
+        if (s->strip_order_capacity < strip_table.size()) {
+            if (s->d_strip_order) (void)hipFree(s->d_strip_order);
+            s->d_strip_order = nullptr;
+            s->strip_order_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&s->d_strip_order, strip_table.size() * sizeof(uint64_t)));
+            s->strip_order_capacity = strip_table.size();
+        }
+        HIP_TRY(hipMemcpy(s->d_strip_order, strip_table.data(), strip_table.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        s->plan_valid = true;
+        job->strip_order = s->d_strip_order;
+        return RTC_OK;
+    }
     if (s->tile_order_capacity < local_tiles) {
         if (s->d_tile_order) (void)hipFree(s->d_tile_order);
         s->d_tile_order = nullptr;

@@ -180,6 +180,9 @@ struct DevJob {
     // Order in which the queue hands out the local tiles (queue slot -> local tile index),
     // costliest first, or nullptr for the natural order.  Only the schedule depends on it.
     const uint32_t* tile_order;
+    // The queue dealt in strips of 8 x 2 pixels instead (four entries per chunk of 64 queue positions; see
+    // build_strip_order in rtc_api.hip for the entry format), or nullptr.  Takes precedence over tile_order.
+    const unsigned long long* strip_order;
     int32_t depth;
     int32_t weighted;  // 1: the attenuation-weighted integrator (render_weighted_kernel) instead of the post-order one
     double* out;
