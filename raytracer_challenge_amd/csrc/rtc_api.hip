@@ -748,8 +748,15 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
     const int strips = (strips_usable(cam) && !(s->canvas_store == RTC_CANVAS_STORE_BLOCKS && job->out_row_major))
                            ? strip_queue_variant(job, local_tiles)
                            : 0;
-    if (s->plan_valid && s->plan_rank == job->tile_rank && s->plan_ranks == job->tile_ranks && s->plan_strips == strips &&
-        s->plan_row_major == (job->out_row_major != 0) && std::memcmp(&s->plan_camera, cam, sizeof *cam) == 0) {
+    // A new camera gets the order of the tiles (little host arithmetic, 65 KB at 4K); the strip table (2 ms of host
+    // work and 4 MB at 4K) is made when the same camera comes a second time, so that a moving camera never pays for it
+    // and a still one pays once.
+    // (a cached strip table is of no use to a launch that must not have one: block stores selected meanwhile)
+    const bool same = s->plan_valid && s->plan_rank == job->tile_rank && s->plan_ranks == job->tile_ranks &&
+                      s->plan_row_major == (job->out_row_major != 0) && (strips != 0 || !s->plan_has_strips) &&
+                      std::memcmp(&s->plan_camera, cam, sizeof *cam) == 0;
+    const bool upgrade = same && strips != 0 && s->plan_strips != strips;
+    if (same && !upgrade) {
         job->tile_order = s->plan_identity ? nullptr : s->d_tile_order;
         job->strip_order = s->plan_has_strips ? s->d_strip_order : nullptr;
         if (job->strip_order) job->tile_order = nullptr;
@@ -759,13 +766,13 @@ int plan_tile_order(RtcScene* s, const RtcCameraDesc* cam, rtc::DevJob* job, uin
     std::vector<PixelBox> boxes;
     if (int rc = compute_tile_order(s, cam, job, local_tiles, order, &boxes)) return rc;
     std::vector<uint64_t> strip_table;
-    if (strips != 0 && !boxes.empty()) build_strip_order(cam, job, local_tiles, order, boxes, strips, strip_table);
+    if (upgrade && !boxes.empty()) build_strip_order(cam, job, local_tiles, order, boxes, strips, strip_table);
     // the cache describes a plan only once that plan is on the device (or needs no upload)
     s->plan_valid = false;
     s->plan_camera = *cam;
     s->plan_rank = job->tile_rank;
     s->plan_ranks = job->tile_ranks;
-    s->plan_strips = strips;
+    s->plan_strips = upgrade ? strips : 0;  // (the variant the plan was made for once the camera had repeated)
     s->plan_row_major = job->out_row_major != 0;
     s->plan_identity = order.empty();
     s->plan_has_strips = !strip_table.empty();
@@ -1049,6 +1056,7 @@ int run_job(RtcScene* s, rtc::DevJob& job, hipStream_t stream, RtcStats* stats, 
     const bool block_stores = s->canvas_store == RTC_CANVAS_STORE_BLOCKS && job.out_row_major && !job.weighted && !stats &&
                               job.rays == nullptr && s->d_flush_stage != nullptr;
     job.flush_stage = block_stores ? s->d_flush_stage : nullptr;
+    if (block_stores) job.strip_order = nullptr;  // (a block must stay with one wave; plan_tile_order does not hand one out then)
     job.flush_waves = block_stores ? s->flush_waves : 0u;
     if (job.weighted && job.out_row_major && job.tile_ranks > 1)
         return fail(RTC_ERR_INVALID_ARGUMENT,

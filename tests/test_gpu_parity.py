@@ -723,6 +723,48 @@ def test_value_identical_shapes_are_rejected():  # calc.zig:274,280 identify obj
     assert e.value.code == D.RTC_ERR_DUPLICATE_SHAPE
 
 
+def test_a_camera_that_repeats_gets_the_queue_in_strips():
+    """The queue plan of a scene handle: a new camera gets the order of the tiles, the same camera a second time the
+    strip table (8 x 2 pixel strips; on small shares a costly block's strips are dealt among ordinary ones, on larger
+    frames costly blocks come first), later frames reuse it.  Only the schedule may change: every frame of the
+    sequence is the oracle's canvas, whole and in a three-way partition, at sizes on either side of the rule that
+    picks the variant, and again after another camera and after block stores were switched on and off."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    w, small = scenes.draw_world_scene(640, 360)      # 3 600 blocks: one costly strip with three ordinary ones
+    _, large = scenes.draw_world_scene(1920, 1080)    # 32 400 blocks: costly blocks first
+    want_small = O.render(w, small, 5, O.STREAMING)
+    rows = (7, 1080, 97)
+    want_large = O.render(w, large, 5, O.STREAMING, rows=rows)
+    with scene_of(w) as sc:
+        for _ in range(3):
+            assert_identical(sc.render(small.desc(), 5), want_small, "640x360, repeated camera")
+        first = sc.render(large.desc(), 5)
+        assert_identical(first[rows[0]::rows[2]], want_large[rows[0]::rows[2]], "1920x1080 against the oracle's rows")
+        for k in range(3):
+            assert np.array_equal(sc.render(large.desc(), 5), first), f"1920x1080, frame {k + 2} with the same camera"
+        assert_identical(sc.render(small.desc(), 5), want_small, "back to the small camera")
+        sc.set_canvas_store(D.RTC_CANVAS_STORE_BLOCKS)
+        assert np.array_equal(sc.render(large.desc(), 5), first) and np.array_equal(sc.render(large.desc(), 5), first)
+        sc.set_canvas_store(D.RTC_CANVAS_STORE_PIXELS)
+        assert np.array_equal(sc.render(large.desc(), 5), first) and np.array_equal(sc.render(large.desc(), 5), first)
+        # a rank's share, rendered four times in a row into its dense tile buffer and in place into a canvas
+        cd = small.desc()
+        canvas = torch.full((cd.hsize * cd.vsize * 3,), -7.0, dtype=torch.float64, device=dev)
+        for rank in range(3):
+            n = native.tile_buffer_doubles(cd, rank, 3)
+            tiles = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(4)]
+            for t in tiles:
+                sc.render_device(cd, 5, t.data_ptr(), rank, 3)
+            torch.cuda.synchronize()
+            assert all(torch.equal(t, tiles[0]) for t in tiles[1:]), f"rank {rank} of 3, tile buffer"
+            for _ in range(3):
+                sc.render_device_to_canvas(cd, 5, canvas.data_ptr(), rank, 3)
+            torch.cuda.synchronize()
+        assert_identical(canvas.cpu().numpy().reshape(cd.vsize, cd.hsize, 3), want_small, "three ranks in place, repeated")
+
+
 def test_one_scene_many_cameras():
     """The queue order is planned per camera from where the transparent shapes project to and is
     cached in the scene handle: different cameras on one handle (glass in view, off to a side,
