@@ -864,6 +864,15 @@ __device__ __forceinline__ unsigned long long in_visiting_order64(unsigned long 
 #define RTC_VOTE_NUM 1  // the sphere tests get the trip when (lanes with a sphere waiting) x DEN >= (lanes with a block to do) x NUM
 #define RTC_VOTE_DEN 2  // (measured: 1:4, 1:2, 1:1, 2:1 within 4 % of each other, 1:2 the fastest)
 #endif
+// (the statistics build keeps the line form of the packed tests, see pair_clear; the developer build RTC_ITEM_STATS
+// counts the items of the work loop as the frame kernels see them, with the segment form, in two statistics slots)
+#ifdef RTC_ITEM_STATS
+template <bool STATS>
+constexpr bool kSegmentForm = true;
+#else
+template <bool STATS>
+constexpr bool kSegmentForm = !STATS;
+#endif
 template <bool SHADOW, bool STATS>
 __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pairs, const double* __restrict__ bounds,
                                                     const double* __restrict__ inv, const int* __restrict__ order_of,
@@ -921,10 +930,10 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         r.a = a;
         r.b = b;
         bool c0, c1, c2, c3, c4, c5, c6, c7;
-        pair_clear<SHADOW, !STATS>(v, r, c0, c1);
-        pair_clear<SHADOW, !STATS>(v + 8, r, c2, c3);
-        pair_clear<SHADOW, !STATS>(v + 16, r, c4, c5);
-        pair_clear<SHADOW, !STATS>(v + 24, r, c6, c7);
+        pair_clear<SHADOW, kSegmentForm<STATS>>(v, r, c0, c1);
+        pair_clear<SHADOW, kSegmentForm<STATS>>(v + 8, r, c2, c3);
+        pair_clear<SHADOW, kSegmentForm<STATS>>(v + 16, r, c4, c5);
+        pair_clear<SHADOW, kSegmentForm<STATS>>(v + 24, r, c6, c7);
         return (c0 ? 0u : 1u) | (c1 ? 0u : 2u) | (c2 ? 0u : 4u) | (c3 ? 0u : 8u) | (c4 ? 0u : 16u) | (c5 ? 0u : 32u) |
                (c6 ? 0u : 64u) | (c7 ? 0u : 128u);
     };
@@ -967,12 +976,14 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                     // the statistics build runs it, to count as the other sweeps do.  The full test finds the same
                     // spheres without roots.
                     bool clear = false;
+#ifndef RTC_ITEM_STATS
                     if (STATS) {
                         const double* __restrict__ b = bounds + (size_t)(uint32_t)i * 4;
                         const double bb[4] = {b[0], b[1], b[2], b[3]};
                         clear = SHADOW ? sphere_clear_of_shadow_ray(bb, bb[3], d, shadow_margin) : sphere_clear_of_ray(bb, bb[3], o, d, dd);
                         if (clear) ++ctr.sphere_skips;
                     }
+#endif
                     if (!clear) {
                         ShapeRec rec;
                         const double* __restrict__ m = inv + (size_t)(uint32_t)i * 12;
@@ -1020,6 +1031,24 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                 const uint32_t real = real_bits(first, unit_log2);
                 const uint32_t open = eight(src, level == 0 ? r32.a : a_blocks, level == 0 ? r32.b : b_blocks) & real;
                 if (STATS) count_dismissed(real & ~open, first, unit_log2);
+#ifdef RTC_ITEM_STATS
+                if (STATS) {
+                    ++ctr.cube_hits;                   // items of the work loop
+                    if (open == 0u) ++ctr.sphere_hits;  // ... none of whose eight entries survived
+                    // would the item's OWN bound, tested again with the stretch as it is now, have dismissed it?
+                    const uint32_t own_table = level == 0 ? block_pairs_offset : (level == 1 ? super_pairs_offset : group_pairs_offset);
+                    const uint32_t own = (uint32_t)first >> (3 * (level + 1));
+                    const float* __restrict__ e = pairs + ((size_t)own_table + (size_t)(own >> 1) * 8 + (own & 1u));
+                    const float one[8] = {e[0], e[0], e[2], e[2], e[4], e[4], e[6], e[6]};
+                    Ray32 rr = r32;
+                    rr.a = a_blocks;
+                    rr.b = b_blocks;
+                    bool d0, d1;
+                    pair_clear<SHADOW, true>(one, rr, d0, d1);
+                    if (d0) ++ctr.sphere_skips;
+                    if (d0 && open != 0u) ++ctr.plane_hits;  // (must never happen: the parent's test implies the children's)
+                }
+#endif
                 cands = level == 0 ? open : 0u;
                 cands_first = level == 0 ? first : cands_first;
                 sub |= level == 0 ? 0u : in_visiting_order8(open, (order_mask >> (3 * level)) & 7u) << (8 * (level - 1));
@@ -1039,10 +1068,10 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         asm volatile("" ::"s"(G.v[31]) : "memory");
         const Pairs4 N = load_pairs4(g + 32);
         bool b0, b1, b2, b3, b4, b5, b6, b7;
-        pair_clear<SHADOW, !STATS>(G.v, r32s, b0, b1);
-        pair_clear<SHADOW, !STATS>(G.v + 8, r32s, b2, b3);
-        pair_clear<SHADOW, !STATS>(G.v + 16, r32s, b4, b5);
-        pair_clear<SHADOW, !STATS>(G.v + 24, r32s, b6, b7);
+        pair_clear<SHADOW, kSegmentForm<STATS>>(G.v, r32s, b0, b1);
+        pair_clear<SHADOW, kSegmentForm<STATS>>(G.v + 8, r32s, b2, b3);
+        pair_clear<SHADOW, kSegmentForm<STATS>>(G.v + 16, r32s, b4, b5);
+        pair_clear<SHADOW, kSegmentForm<STATS>>(G.v + 24, r32s, b6, b7);
         const uint32_t real = real_bits(i, top_log2);  // wave-uniform
         const uint32_t need = ((b0 ? 0u : 1u) | (b1 ? 0u : 2u) | (b2 ? 0u : 4u) | (b3 ? 0u : 8u) | (b4 ? 0u : 16u) |
                                (b5 ? 0u : 32u) | (b6 ? 0u : 64u) | (b7 ? 0u : 128u)) & real;
