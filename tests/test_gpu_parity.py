@@ -765,6 +765,32 @@ def test_a_camera_that_repeats_gets_the_queue_in_strips():
         assert_identical(canvas.cpu().numpy().reshape(cd.vsize, cd.hsize, 3), want_small, "three ranks in place, repeated")
 
 
+def test_repeated_cameras_on_ragged_canvases():
+    """The strip table on canvases whose sides are no multiples of a strip (8 x 2), a block (8 x 8) or a tile: strips
+    that hang over the right or lower edge, tiles past the last one of a rank's share, a canvas smaller than one strip.
+    Every frame of a camera that repeats (tile order first, strips from the second frame on) is the oracle's canvas,
+    whole and as two ranks' shares stored in place."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    w, _ = scenes.draw_world_scene(64, 32)
+    frm, to = (-2.6, 1.5, -3.9), (-0.6, 1, -0.8)
+    with scene_of(w) as sc:
+        for hs, vs in ((333, 17), (130, 70), (97, 131), (17, 3), (8, 2), (5, 1), (1, 1), (263, 9)):
+            cam = Camera(hs, vs, 1.152)
+            cam.transform = view_transform(init_point(*frm), init_point(*to), init_vector(0, 1, 0))
+            want = O.render(w, cam, 5, O.STREAMING)
+            cd = cam.desc()
+            for k in range(3):
+                assert_identical(sc.render(cd, 5).reshape(vs, hs, 3), want, f"{hs}x{vs}, frame {k + 1}")
+            canvas = torch.full((hs * vs * 3,), -7.0, dtype=torch.float64, device=dev)
+            for rank in range(2):
+                for _ in range(3):
+                    sc.render_device_to_canvas(cd, 5, canvas.data_ptr(), rank, 2)
+            torch.cuda.synchronize()
+            assert_identical(canvas.cpu().numpy().reshape(vs, hs, 3), want, f"{hs}x{vs}, two ranks in place, repeated")
+
+
 def test_one_scene_many_cameras():
     """The queue order is planned per camera from where the transparent shapes project to and is
     cached in the scene handle: different cameras on one handle (glass in view, off to a side,
