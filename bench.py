@@ -357,6 +357,11 @@ def main():
             else:
                 dist.broadcast(handle, src=0)
             if rank != 0:
+                # a kernel that stores through a mapping its GPU cannot address faults the GPU: ask first
+                # (torch.distributed.run leaves every GPU visible, so rank 0's GPU is device 0 here too)
+                if (not args.rehearse_on_one_gpu and local_rank != 0 and torch.cuda.device_count() > 1
+                        and not torch.cuda.can_device_access_peer(local_rank, 0)):
+                    raise RuntimeError(f"GPU {local_rank} cannot address the memory of GPU 0")
                 peer_canvas = native.ipc_canvas_open(bytes(handle.cpu().numpy().tobytes()))
         except Exception as e:  # no peer mapping on this machine: the leg is reported as unavailable
             peer_why = f"{type(e).__name__}: {e}"
