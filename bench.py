@@ -181,6 +181,32 @@ def weighted_integrator_leg(torch, native, D, scene, cam, args, exact, stream, r
             "max_8bit_difference": int(d8.max()), "within_stated_tolerance": ok}
 
 
+def frames_in_flight_leg(torch, native, D, world, cam, args, exact, radiance_rays):
+    """A stream of frames instead of one frame at a time: two scene handles of the same world (a handle owns its
+    work queue, so a handle has one frame in flight), two streams, two canvases, frames launched alternately.  The
+    waves of the next frame start on the compute units the tail of the current frame leaves idle.  Every frame is
+    complete and both canvases are compared with the headline's; reported beside the headline, which stays the
+    time of one frame on its own."""
+    scenes_ = [native.Scene(world.shape_descs(), len(world.objects), world.light_desc()) for _ in range(2)]
+    try:
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        outs = [torch.empty_like(exact) for _ in range(2)]
+        for k in range(2 * max(args.warmup, 3)):
+            scenes_[k % 2].render_device(cam, args.depth, outs[k % 2].data_ptr(), 0, 1, streams[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            scenes_[k % 2].render_device(cam, args.depth, outs[k % 2].data_ptr(), 0, 1, streams[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / max(args.steps, 1)
+        ok = bool(torch.equal(outs[0], exact) and torch.equal(outs[1], exact))
+    finally:
+        for sc in scenes_:
+            sc.close()
+    return {"frames_in_flight": 2, "ms_per_frame": ms if ok else None,
+            "rays_per_s": radiance_rays / (ms * 1e-3) if ok else None, "canvases_identical_to_the_headline_s": ok}
+
+
 def cpu_baseline(world, camera, depth, budget_s=20.0):
     """Single-thread CPU baseline on this host: the oracle (a port of the reference) on a
     bounded sample of the same frame.  Pixels are sampled with a fixed stride; the literal
@@ -770,6 +796,9 @@ def main():
         if world_size == 1 and not args.accel and not weighted:
             out["config"]["weighted_integrator"] = weighted_integrator_leg(torch, native, D, scene, cam, args, local, stream,
                                                                            total["radiance_rays"])
+        if world_size == 1 and not args.accel and not weighted:
+            out["config"]["stream_of_frames"] = frames_in_flight_leg(torch, native, D, world, cam, args, local,
+                                                                     total["radiance_rays"])
         if world_size == 1 and args.multi_ranks > 0:
             out["config"]["single_process_multi"] = single_process_multi(native, D, world, cam, args, hsize, vsize)
         if world_size == 1 and not args.no_cpu_baseline:

@@ -791,6 +791,27 @@ def test_repeated_cameras_on_ragged_canvases():
             assert_identical(canvas.cpu().numpy().reshape(vs, hs, 3), want, f"{hs}x{vs}, two ranks in place, repeated")
 
 
+def test_two_handles_render_concurrently_on_two_streams():
+    """A scene handle has one frame in flight (it owns the work queue of its launch); two handles of the same world
+    on two streams overlap their frames, the waves of one starting where the tail of the other leaves compute units
+    idle.  Alternating launches without any synchronisation in between: every canvas is the oracle's."""
+    import torch
+
+    w, cam = scenes.draw_world_scene(320, 180)
+    want = O.render(w, cam, 5, O.STREAMING)
+    cd = cam.desc()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    with scene_of(w) as a, scene_of(w) as b:
+        handles = (a, b)
+        outs = [[torch.full((cd.hsize * cd.vsize * 3,), -3.0, dtype=torch.float64, device="cuda") for _ in range(4)] for _ in range(2)]
+        for k in range(8):
+            handles[k % 2].render_device(cd, 5, outs[k % 2][k // 2].data_ptr(), 0, 1, streams[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        for h in range(2):
+            for k, t in enumerate(outs[h]):
+                assert_identical(t.cpu().numpy().reshape(cd.vsize, cd.hsize, 3), want, f"handle {h}, frame {k + 1}")
+
+
 def test_one_scene_many_cameras():
     """The queue order is planned per camera from where the transparent shapes project to and is
     cached in the scene handle: different cameras on one handle (glass in view, off to a side,
