@@ -365,16 +365,13 @@ def main():
 
     # third leg for N > 1: no gather at all.  Rank 0's canvas is mapped into every rank's address space
     # (HIP IPC) and each rank's render kernel stores its pixels at their final place in it over xGMI.
-    peer_canvas = None       # device pointer of rank 0's canvas as this process addresses it
-    peer_why = None
-    peer_canvas_usable = False
-    if world_size > 1 and weighted:
-        peer_why = "the weighted integrator does not render in place into a shared canvas"
-    if world_size > 1 and not weighted:
+    def share_a_canvas():
+        """Rank 0 allocates a canvas and every other rank maps it (HIP IPC): (pointer in this process or None, why not)."""
+        mapped, why = None, None
         try:
             handle = torch.zeros(D.RTC_IPC_HANDLE_BYTES, dtype=torch.uint8, device=dev)
             if rank == 0:
-                peer_canvas, hbytes = native.ipc_canvas_create(hsize * vsize * 3 * 8)
+                mapped, hbytes = native.ipc_canvas_create(hsize * vsize * 3 * 8)
                 handle.copy_(torch.frombuffer(bytearray(hbytes), dtype=torch.uint8))
             if args.rehearse_on_one_gpu:
                 hcpu = handle.cpu()
@@ -388,17 +385,26 @@ def main():
                 if (not args.rehearse_on_one_gpu and local_rank != 0 and torch.cuda.device_count() > 1
                         and not torch.cuda.can_device_access_peer(local_rank, 0)):
                     raise RuntimeError(f"GPU {local_rank} cannot address the memory of GPU 0")
-                peer_canvas = native.ipc_canvas_open(bytes(handle.cpu().numpy().tobytes()))
+                mapped = native.ipc_canvas_open(bytes(handle.cpu().numpy().tobytes()))
         except Exception as e:  # no peer mapping on this machine: the leg is reported as unavailable
-            peer_why = f"{type(e).__name__}: {e}"
-            peer_canvas = None
-        ok = torch.tensor([1 if peer_canvas else 0], dtype=torch.int32, device="cpu" if args.rehearse_on_one_gpu else dev)
+            why = f"{type(e).__name__}: {e}"
+            mapped = None
+        ok = torch.tensor([1 if mapped else 0], dtype=torch.int32, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
-            peer_why = peer_why or "another rank could not map the canvas"
-            peer_canvas_usable = False
-        else:
-            peer_canvas_usable = True
+            return mapped, False, why or "another rank could not map the canvas"
+        return mapped, True, None
+
+    peer_canvas = None       # device pointer of rank 0's canvas as this process addresses it
+    peer_canvas2 = None      # a second one, for the leg that keeps two frames in flight
+    peer_why = None
+    peer_canvas_usable = peer_canvas2_usable = False
+    if world_size > 1 and weighted:
+        peer_why = "the weighted integrator does not render in place into a shared canvas"
+    if world_size > 1 and not weighted:
+        peer_canvas, peer_canvas_usable, peer_why = share_a_canvas()
+        if peer_canvas_usable:
+            peer_canvas2, peer_canvas2_usable, _ = share_a_canvas()
     # fourth leg for N > 1: no GPU-to-GPU traffic at all.  Every rank copies its dense tile buffer to pinned
     # host memory of its own over its GPU's own PCIe link; the tiles of the frame then lie in N host buffers
     # (in one process, rtc_render_multi's RTC_MULTI_HOST_DIRECT scatters them into one host canvas instead).
@@ -545,6 +551,36 @@ def main():
         fence()
         elapsed_peer = time.perf_counter() - t0
 
+    # The peer-store leg as a stream of frames: two scene handles, two streams and two shared canvases per rank,
+    # frames launched alternately, so that the tail of one frame's share (the serial chains of single glass pixels)
+    # overlaps with the next frame's start on every GPU.  No per-frame completion token here: the ranks meet once,
+    # after the last frame (a consumer on rank 0 would need one per frame, on a third stream).
+    elapsed_stream = 0.0
+    stream_copies = None
+    if world_size > 1 and peer_canvas_usable and peer_canvas2_usable:
+        scene2 = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
+        second = torch.cuda.Stream()
+        lanes_ = ((scene, peer_canvas, stream), (scene2, peer_canvas2, second.cuda_stream))
+        for k in range(2 * max(args.warmup, 3)):
+            h, c, st_ = lanes_[k % 2]
+            h.render_device_to_canvas(cam, args.depth, c, rank, world_size, st_)
+        torch.cuda.synchronize()
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            h, c, st_ = lanes_[k % 2]
+            h.render_device_to_canvas(cam, args.depth, c, rank, world_size, st_)
+        torch.cuda.synchronize()  # this rank's stores have arrived ...
+        fence()                   # ... and so have everybody else's
+        elapsed_stream = time.perf_counter() - t0
+        if rank == 0:
+            stream_copies = [_device_view(torch, c, hsize * vsize * 3, dev).clone() for c in (peer_canvas, peer_canvas2)]
+        scene2.close()
+        fence()
+        # (the canvas of the per-pixel peer leg is put back for the comparison below)
+        render_into_peer_canvas()
+        fence()
+
     elapsed_host = 0.0
     if world_size > 1 and local_host is not None:
         for _ in range(max(args.warmup, 1)):
@@ -565,7 +601,8 @@ def main():
         step()
         fence()
 
-    t = torch.tensor([elapsed, kernel_ms, elapsed_u8, elapsed_peer, elapsed_host, elapsed_peer_blocks], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms, elapsed_u8, elapsed_peer, elapsed_host, elapsed_peer_blocks, elapsed_stream],
+                     dtype=torch.float64, device=dev)
     if world_size > 1:
         if args.rehearse_on_one_gpu:
             tc = t.cpu()
@@ -573,7 +610,8 @@ def main():
             t = tc
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max, kernel_ms_max, elapsed_u8_max, elapsed_peer_max, elapsed_host_max, elapsed_peer_blocks_max = (float(v) for v in t.tolist())
+    (elapsed_max, kernel_ms_max, elapsed_u8_max, elapsed_peer_max, elapsed_host_max, elapsed_peer_blocks_max,
+     elapsed_stream_max) = (float(v) for v in t.tolist())
     # how even the shares are: every rank's own kernel time and ray count (an uneven partition shows here)
     mine = torch.tensor([kernel_ms, float(st.radiance_rays)], dtype=torch.float64,
                         device="cpu" if (world_size > 1 and args.rehearse_on_one_gpu) else dev)
@@ -586,7 +624,7 @@ def main():
 
     # Every N > 1 run checks what it assembled: rank 0 renders the whole frame alone (outside the timed
     # regions) and compares the canvases value for value.  A leg that differs is not reported.
-    gather_ok = peer_ok = host_ok = peer_blocks_ok = None
+    gather_ok = peer_ok = host_ok = peer_blocks_ok = stream_ok = None
     if world_size > 1 and rank == 0:
         whole = torch.empty(hsize * vsize * 3, dtype=torch.float64, device=dev)
         scene.render_device(cam, args.depth, whole.data_ptr(), 0, 1, stream)
@@ -598,6 +636,7 @@ def main():
             peer_t = _device_view(torch, peer_canvas, hsize * vsize * 3, dev)
             peer_ok = bool(torch.equal(whole, peer_t))
             peer_blocks_ok = bool(torch.equal(whole, peer_blocks_copy)) if peer_blocks_copy is not None else None
+            stream_ok = all(bool(torch.equal(whole, c)) for c in stream_copies) if stream_copies is not None else None
 
     if world_size > 1 and rank == 0:
         q = torch.empty(hsize * vsize * 3, dtype=torch.uint8, device=dev)
@@ -609,9 +648,10 @@ def main():
         else:
             u8_ok = bool(torch.equal(q, canvas_u8))
         if args.verify:
-            if not (gather_ok and u8_ok and peer_ok is not False and host_ok is not False and peer_blocks_ok is not False):
+            if not (gather_ok and u8_ok and peer_ok is not False and host_ok is not False and peer_blocks_ok is not False
+                    and stream_ok is not False):
                 raise SystemExit(f"verify FAILED: gather {gather_ok}, 8-bit gather {u8_ok}, peer stores {peer_ok}, "
-                                 f"own D2H {host_ok}")
+                                 f"own D2H {host_ok}, block stores {peer_blocks_ok}, stream of frames {stream_ok}")
             print(f"verify ok: assembled canvases identical to the 1-rank render (f64 gather, 8-bit gather, "
                   f"peer stores: {peer_ok}, own D2H: {host_ok})", file=sys.stderr)
 
@@ -785,6 +825,13 @@ def main():
             out["config"]["frame_ms_with_peer_stores"] = ms_peer
             out["config"]["frame_ms_with_peer_block_stores"] = ms_peer_blocks
             out["config"]["peer_stores_unavailable_because"] = peer_why
+            # never the headline: a stream of frames (two in flight per GPU), not one frame on its own
+            ms_stream = elapsed_stream_max * 1e3 / args.steps if stream_ok else None
+            out["config"]["stream_of_frames"] = {
+                "frames_in_flight": 2, "ms_per_frame": ms_stream,
+                "rays_per_s": total["radiance_rays"] / (ms_stream * 1e-3) if ms_stream else None,
+                "how": "peer stores into two shared canvases on rank 0, two scene handles and two streams per rank, "
+                       "the ranks meet after the last frame"}
             # every GPU copying its own tiles to pinned host memory, no gather (never the headline: the other legs
             # leave the canvas on rank 0's GPU, this one ends in N host buffers and includes the trip over PCIe)
             out["config"]["frame_ms_with_own_d2h_no_gather"] = (
@@ -792,7 +839,8 @@ def main():
             out["config"]["own_d2h_unavailable_because"] = host_why
             out["config"]["canvases_verified_against_1_rank_render"] = {"f64_gather": gather_ok, "u8_gather": u8_ok,
                                                                         "peer_stores": peer_ok, "own_d2h": host_ok,
-                                                                        "peer_block_stores": peer_blocks_ok}
+                                                                        "peer_block_stores": peer_blocks_ok,
+                                                                        "stream_of_frames": stream_ok}
         if world_size == 1 and not args.accel and not weighted:
             out["config"]["weighted_integrator"] = weighted_integrator_leg(torch, native, D, scene, cam, args, local, stream,
                                                                            total["radiance_rays"])
@@ -811,11 +859,13 @@ def main():
     if world_size > 1:
         torch.cuda.synchronize()
         dist.barrier()
-        if peer_canvas and rank != 0:
-            native.ipc_canvas_close(peer_canvas, False)
+        for c in (peer_canvas, peer_canvas2):
+            if c and rank != 0:
+                native.ipc_canvas_close(c, False)
         dist.barrier()
-        if peer_canvas and rank == 0:
-            native.ipc_canvas_close(peer_canvas, True)
+        for c in (peer_canvas, peer_canvas2):
+            if c and rank == 0:
+                native.ipc_canvas_close(c, True)
         dist.destroy_process_group()
 
 

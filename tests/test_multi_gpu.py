@@ -143,7 +143,8 @@ def test_one_process_per_rank_front_end_with_ipc_canvas():
     with two ranks that share the one GPU and a gloo gather through the host: the f64 gather, the 8-bit
     gather, the peer-store leg (rank 0's canvas mapped into rank 1 with rtc_ipc_canvas_create/open,
     rtc_render_device_to_canvas from both processes) and the leg without a gather (every rank copies its tiles to pinned host
-    memory of its own) must all reproduce the 1-rank canvas."""
+    memory of its own) and the peer-store leg as a stream of frames (two handles, two streams and two shared canvases
+    per rank) must all reproduce the 1-rank canvas."""
     import json
     import os
     import subprocess
@@ -167,7 +168,9 @@ def test_one_process_per_rank_front_end_with_ipc_canvas():
     assert out["n_gpus"] == 2
     assert out["config"]["canvases_verified_against_1_rank_render"] == {"f64_gather": True, "u8_gather": True,
                                                                         "peer_stores": True, "own_d2h": True,
-                                                                        "peer_block_stores": True}
+                                                                        "peer_block_stores": True,
+                                                                        "stream_of_frames": True}
+    assert out["config"]["stream_of_frames"]["ms_per_frame"] > 0
 
 
 def test_block_stores_give_the_same_canvas():
