@@ -181,6 +181,29 @@ def weighted_integrator_leg(torch, native, D, scene, cam, args, exact, stream, r
             "max_8bit_difference": int(d8.max()), "within_stated_tolerance": ok}
 
 
+def two_streams_that_overlap(torch, launch):
+    """Two streams whose kernels run side by side.  The runtime deals its streams over a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default) and launches of streams that share a queue run one after the other, so a
+    pair is picked by measurement: a few alternating launches (`launch(which, stream)`, which = 0 or 1) with one
+    stream and each of three partners, the fastest pair wins."""
+    first = torch.cuda.Stream()
+    best = None
+    for _ in range(3):
+        partner = torch.cuda.Stream()
+        pair = (first, partner)
+        for k in range(4):
+            launch(k % 2, pair[k % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(6):
+            launch(k % 2, pair[k % 2])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, partner)
+    return first, best[1]
+
+
 def frames_in_flight_leg(torch, native, D, world, cam, args, exact, radiance_rays):
     """A stream of frames instead of one frame at a time: two scene handles of the same world (a handle owns its
     work queue, so a handle has one frame in flight), two streams, two canvases, frames launched alternately.  The
@@ -189,8 +212,9 @@ def frames_in_flight_leg(torch, native, D, world, cam, args, exact, radiance_ray
     time of one frame on its own."""
     scenes_ = [native.Scene(world.shape_descs(), len(world.objects), world.light_desc()) for _ in range(2)]
     try:
-        streams = [torch.cuda.Stream() for _ in range(2)]
         outs = [torch.empty_like(exact) for _ in range(2)]
+        streams = two_streams_that_overlap(
+            torch, lambda which, st: scenes_[which].render_device(cam, args.depth, outs[which].data_ptr(), 0, 1, st.cuda_stream))
         for k in range(2 * max(args.warmup, 3)):
             scenes_[k % 2].render_device(cam, args.depth, outs[k % 2].data_ptr(), 0, 1, streams[k % 2].cuda_stream)
         torch.cuda.synchronize()
@@ -559,8 +583,10 @@ def main():
     stream_copies = None
     if world_size > 1 and peer_canvas_usable and peer_canvas2_usable:
         scene2 = native.Scene(world.shape_descs(), len(world.objects), world.light_desc())
-        second = torch.cuda.Stream()
-        lanes_ = ((scene, peer_canvas, stream), (scene2, peer_canvas2, second.cuda_stream))
+        both = (scene, scene2), (peer_canvas, peer_canvas2)
+        pair = two_streams_that_overlap(
+            torch, lambda which, st_: both[0][which].render_device_to_canvas(cam, args.depth, both[1][which], rank, world_size, st_.cuda_stream))
+        lanes_ = ((scene, peer_canvas, pair[0].cuda_stream), (scene2, peer_canvas2, pair[1].cuda_stream))
         for k in range(2 * max(args.warmup, 3)):
             h, c, st_ = lanes_[k % 2]
             h.render_device_to_canvas(cam, args.depth, c, rank, world_size, st_)

@@ -34,7 +34,7 @@ for ranks in (1, 2, 4, 8):
     if "--stream" in sys.argv:
         import time
         handles = [native.Scene(world.shape_descs(), len(world.objects), world.light_desc()) for _ in range(2)]
-        streams = [torch.cuda.Stream() for _ in range(2)]
+        streams = globals().setdefault('_two_streams', [torch.cuda.Stream() for _ in range(2)])  # (the same two for every share size)
         outs = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(2)]
         for k in range(8):
             handles[k % 2].render_device(cd, 5, outs[k % 2].data_ptr(), 0, ranks, streams[k % 2].cuda_stream)
