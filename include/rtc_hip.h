@@ -211,7 +211,10 @@ int rtc_scene_group_counts(const RtcScene* scene, uint64_t out_counts[RTC_SWEEP_
  * reference hard-codes depth 5 (camera.zig:83).  depth is the reference's i32 `remaining`
  * (calc.zig:641): a value <= 0 spawns no secondary rays (calc.zig:829,946), so a negative depth
  * renders like depth 0; the largest supported depth is 16 (RTC_ERR_TOO_LARGE beyond).  This holds
- * for every entry point that takes a depth.  stats may be NULL.
+ * for every entry point that takes a depth.  stats may be NULL.  The call returns when out_rgb is
+ * complete.  A canvas of 64 MB and more is rendered in several launches (bands of rows, on streams
+ * of the scene's own) while earlier bands cross to the host, unless stats is given (the counters are
+ * those of one launch on the NULL stream, as for smaller canvases).
  *
  * Concurrency (all render entry points): the launches of one scene share the scene's control
  * block, tile plan, timing events and staging buffers.  At most one launch per scene may be in

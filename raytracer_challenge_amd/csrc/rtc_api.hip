@@ -237,6 +237,16 @@ struct RtcScene {
     std::vector<hipEvent_t> slice_events;
     double* d_canvas = nullptr;  // device canvas of rtc_render, kept between calls
     size_t canvas_bytes = 0;
+    // rtc_render of a large canvas renders in bands of tile rows (render_to_host_in_bands): its two streams, one event
+    // per band, and the bands' tile lists of the last camera
+    hipStream_t band_render_stream = nullptr, band_copy_stream = nullptr;
+    std::vector<hipEvent_t> band_events;
+    uint32_t* d_band_order = nullptr;
+    uint64_t band_order_capacity = 0;
+    bool band_plan_valid = false;
+    RtcCameraDesc band_camera{};
+    std::vector<uint32_t> band_first;  // per band: where its tiles start in d_band_order (one more entry: the end)
+    std::vector<uint32_t> band_row;    // per band: its first pixel row (one more entry: vsize)
     uint32_t* d_tile_order = nullptr;
     uint64_t tile_order_capacity = 0;
     unsigned long long* d_strip_order = nullptr;  // the queue in strips (build_strip_order), when the plan has one
@@ -263,6 +273,10 @@ void free_scene(RtcScene* s) {
     if (s->d_canvas) (void)hipFree(s->d_canvas);
     if (s->h_staging) (void)hipHostFree(s->h_staging);
     for (hipEvent_t ev : s->slice_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : s->band_events) (void)hipEventDestroy(ev);
+    if (s->band_render_stream) (void)hipStreamDestroy(s->band_render_stream);
+    if (s->band_copy_stream) (void)hipStreamDestroy(s->band_copy_stream);
+    if (s->d_band_order) (void)hipFree(s->d_band_order);
     if (s->d_bvh) (void)hipFree(s->d_bvh);
     if (s->d_flush_stage) (void)hipFree(s->d_flush_stage);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
@@ -972,36 +986,35 @@ void sphere_prefilter_tables(const double bound[4], const double from_light[4], 
 // touch of every page) against 57 GB/s into pinned memory.  Large canvases therefore go through a
 // pinned staging buffer kept with the scene: the device copies it there slice by slice, and a few
 // host threads move finished slices on into the caller's buffer while later slices are in flight.
-int copy_canvas_to_host(RtcScene* s, const void* d_src, void* dst, size_t bytes) {
-    // 16 MiB slices for the large canvases; an 8-bit 4K canvas (25 MB) still gets six
-    const size_t kSlice = bytes >= (64u << 20) ? (16u << 20) : (4u << 20);
-    if (bytes < 4 * kSlice) {
-        HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
-        return RTC_OK;
-    }
-    if (s->staging_bytes < bytes) {
-        if (s->h_staging) (void)hipHostFree(s->h_staging);
+struct HostSlice {
+    size_t begin, len;
+};
+// the pinned staging buffer, grown when needed; false when no pinned memory is to be had
+bool have_staging(RtcScene* s, size_t bytes) {
+    if (s->staging_bytes >= bytes) return true;
+    if (s->h_staging) (void)hipHostFree(s->h_staging);
+    s->h_staging = nullptr;
+    s->staging_bytes = 0;
+    if (hipHostMalloc(&s->h_staging, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
         s->h_staging = nullptr;
-        s->staging_bytes = 0;
-        if (hipHostMalloc(&s->h_staging, bytes, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();  // no pinned memory to be had: the plain copy still works
-            s->h_staging = nullptr;
-            HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
-            return RTC_OK;
-        }
-        s->staging_bytes = bytes;
+        return false;
     }
-    const size_t n_slices = (bytes + kSlice - 1) / kSlice;
-    while (s->slice_events.size() < n_slices) {
+    s->staging_bytes = bytes;
+    return true;
+}
+int have_slice_events(RtcScene* s, size_t n) {
+    while (s->slice_events.size() < n) {
         hipEvent_t ev = nullptr;
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         s->slice_events.push_back(ev);
     }
-    for (size_t k = 0; k < n_slices; ++k) {
-        const size_t begin = k * kSlice, len = std::min(kSlice, bytes - begin);
-        HIP_TRY(hipMemcpyAsync((char*)s->h_staging + begin, (const char*)d_src + begin, len, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipEventRecord(s->slice_events[k], nullptr));
-    }
+    return RTC_OK;
+}
+// Staging buffer -> the caller's buffer, slice k as soon as slice_events[k] has happened, by this thread and a few
+// helpers; returns when every slice is in place (or a wait failed).
+int move_slices_to_caller(RtcScene* s, void* dst, const std::vector<HostSlice>& slices) {
+    const size_t n_slices = slices.size();
     std::atomic<size_t> next{0};
     std::atomic<int> first_error{(int)hipSuccess};
     const int device = s->device;
@@ -1010,24 +1023,59 @@ int copy_canvas_to_host(RtcScene* s, const void* d_src, void* dst, size_t bytes)
         for (;;) {
             const size_t k = next.fetch_add(1);
             if (k >= n_slices) return;
+            const size_t begin = slices[k].begin, len = slices[k].len;
+            {
+                // While the slice is still on its way: touch its pages in the caller's buffer.  A freshly allocated
+                // buffer gets its pages at the first write, which costs more than the move itself (199 MB by one
+                // thread: 16.5 ms into fresh memory, 6.8 ms into touched memory); here that happens while the thread
+                // would be waiting.  (The buffer is output only: every byte touched is overwritten below.)
+                volatile char* d = (volatile char*)dst + begin;
+                for (size_t at = 0; at < len; at += 4096) d[at] = 0;
+                d[len - 1] = 0;
+            }
             const hipError_t e = hipEventSynchronize(s->slice_events[k]);
             if (e != hipSuccess) {
                 int expected = (int)hipSuccess;
                 first_error.compare_exchange_strong(expected, (int)e);
                 return;
             }
-            const size_t begin = k * kSlice, len = std::min(kSlice, bytes - begin);
             std::memcpy((char*)dst + begin, (const char*)s->h_staging + begin, len);
         }
     };
+    static const size_t max_helpers = [] {
+        const char* e = std::getenv("RTC_COPY_HELPERS");  // developer switch for timing
+        if (e && *e) return (size_t)std::atoi(e);
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (size_t)(hw >= 8 ? 7 : (hw >= 4 ? 3 : 1));
+    }();
     std::vector<std::thread> helpers;
-    const size_t n_helpers = std::min<size_t>(3, n_slices - 1);
+    const size_t n_helpers = std::min<size_t>(max_helpers, n_slices - 1);
     for (size_t t = 0; t < n_helpers; ++t) helpers.emplace_back(mover);
     mover();
     for (std::thread& t : helpers) t.join();
-    HIP_TRY(hipStreamSynchronize(nullptr));
     if (first_error.load() != (int)hipSuccess) return fail_hip("copy of the canvas to the host", (hipError_t)first_error.load());
     return RTC_OK;
+}
+
+int copy_canvas_to_host(RtcScene* s, const void* d_src, void* dst, size_t bytes) {
+    // 8 MiB slices for the large canvases (what is left to do once the last slice has arrived is one slice's
+    // move); an 8-bit 4K canvas (25 MB) still gets six
+    const size_t kSlice = bytes >= (64u << 20) ? (8u << 20) : (4u << 20);
+    if (bytes < 4 * kSlice || !have_staging(s, bytes)) {  // (no pinned memory to be had: the plain copy still works)
+        HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+        return RTC_OK;
+    }
+    std::vector<HostSlice> slices;
+    for (size_t begin = 0; begin < bytes; begin += kSlice) slices.push_back({begin, std::min(kSlice, bytes - begin)});
+    if (int rc = have_slice_events(s, slices.size())) return rc;
+    for (size_t k = 0; k < slices.size(); ++k) {
+        HIP_TRY(hipMemcpyAsync((char*)s->h_staging + slices[k].begin, (const char*)d_src + slices[k].begin, slices[k].len,
+                               hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipEventRecord(s->slice_events[k], nullptr));
+    }
+    const int rc = move_slices_to_caller(s, dst, slices);
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return rc;
 }
 
 // Common launch path of rtc_render_device / rtc_render / rtc_color_at.
@@ -1834,6 +1882,96 @@ int rtc_render_device_noalloc(RtcScene* scene, const RtcCameraDesc* camera, int3
     return run_job(scene, job, stream, stats, pixels, control, capturing);
 }
 
+// rtc_render of a large canvas.  One launch followed by the copy leaves the link to the host idle while the kernel
+// runs and the GPU idle while the canvas crosses (4K: 2.1 ms + 3.6 ms, and the moves into the caller's buffer behind
+// that).  Here the frame is rendered in kBands bands of whole tile rows, each band a launch of its own on one stream
+// (the queue of a launch is a list of tiles: plan_tile_order's order, cut by band); a second stream copies a band to
+// the pinned staging buffer as soon as its launch has finished, slice by slice, and the host threads move arrived
+// slices on.  Every pixel is computed by the same arithmetic whichever launch it belongs to.
+const uint32_t kBands = [] {
+    const char* e = std::getenv("RTC_BANDS");  // developer switch for timing
+    const int n = e && *e ? std::atoi(e) : 6;
+    return (uint32_t)(n >= 1 && n <= 64 ? n : 6);
+}();
+// (Not for rtc_render_u8: its 25 MB cross in 0.5 ms, less than six launches instead of one cost - 3.4 against 3.1 ms.)
+int render_to_host_in_bands(RtcScene* s, const RtcCameraDesc* cam, int32_t depth, double* d_out, double* out_host) {
+    rtc::DevJob job{};
+    uint64_t local_pixels = 0;
+    if (int rc = fill_camera_job(cam, depth, 0, 1, &job, &local_pixels)) return rc;
+    job.out = d_out;
+    const uint64_t local_tiles = local_pixels / (RTC_TILE_W * RTC_TILE_H);
+    const uint32_t tiles_x = job.tiles_x, tiles_y = job.tiles_total / job.tiles_x;
+    if (!s->band_render_stream) HIP_TRY(hipStreamCreateWithFlags(&s->band_render_stream, hipStreamNonBlocking));
+    if (!s->band_copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->band_copy_stream, hipStreamNonBlocking));
+    while (s->band_events.size() < kBands) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        s->band_events.push_back(ev);
+    }
+    if (!(s->band_plan_valid && std::memcmp(&s->band_camera, cam, sizeof *cam) == 0)) {
+        s->band_plan_valid = false;
+        // the bands: tile rows dealt evenly; inside a band the tiles keep the order of the whole-frame plan
+        std::vector<uint32_t> order;
+        if (int rc = compute_tile_order(s, cam, &job, local_tiles, order)) return rc;
+        std::vector<uint32_t> band_of_row(tiles_y);
+        s->band_row.assign(kBands + 1, (uint32_t)cam->vsize);
+        for (uint32_t b = 0; b < kBands; ++b) {
+            const uint32_t r0 = (uint32_t)((uint64_t)tiles_y * b / kBands), r1 = (uint32_t)((uint64_t)tiles_y * (b + 1) / kBands);
+            for (uint32_t r = r0; r < r1; ++r) band_of_row[r] = b;
+            s->band_row[b] = std::min<uint32_t>(r0 * RTC_TILE_H, (uint32_t)cam->vsize);
+        }
+        std::vector<uint32_t> count(kBands + 1, 0);
+        for (uint64_t t = 0; t < local_tiles; ++t) ++count[band_of_row[t / tiles_x] + 1];
+        s->band_first.assign(kBands + 1, 0);
+        for (uint32_t b = 0; b < kBands; ++b) s->band_first[b + 1] = s->band_first[b] + count[b + 1];
+        std::vector<uint32_t> at(s->band_first.begin(), s->band_first.end() - 1), list(local_tiles);
+        for (uint64_t k = 0; k < local_tiles; ++k) {
+            const uint32_t t = order.empty() ? (uint32_t)k : order[k];
+            list[at[band_of_row[t / tiles_x]]++] = t;
+        }
+        if (s->band_order_capacity < local_tiles) {
+            if (s->d_band_order) (void)hipFree(s->d_band_order);
+            s->d_band_order = nullptr;
+            s->band_order_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&s->d_band_order, local_tiles * sizeof(uint32_t)));
+            s->band_order_capacity = local_tiles;
+        }
+        // (blocking, from a vector that goes away: launches of an earlier call have been waited for at its end)
+        HIP_TRY(hipMemcpy(s->d_band_order, list.data(), local_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+        s->band_camera = *cam;
+        s->band_plan_valid = true;
+    }
+    const size_t kSlice = 8u << 20, row_bytes = (size_t)cam->hsize * 3 * sizeof(double);
+    const char* d_src = (const char*)d_out;
+    std::vector<HostSlice> slices;
+    std::vector<uint32_t> slices_end(kBands, 0);  // per band: one past its last slice
+    for (uint32_t b = 0; b < kBands; ++b) {
+        const size_t begin = (size_t)s->band_row[b] * row_bytes, end = (size_t)s->band_row[b + 1] * row_bytes;
+        for (size_t at = begin; at < end; at += kSlice) slices.push_back({at, std::min(kSlice, end - at)});
+        slices_end[b] = (uint32_t)slices.size();
+    }
+    if (int rc = have_slice_events(s, slices.size())) return rc;
+    size_t k = 0;
+    for (uint32_t b = 0; b < kBands; ++b) {
+        rtc::DevJob band = job;
+        band.tile_order = s->d_band_order + s->band_first[b];
+        band.strip_order = nullptr;
+        band.total = (s->band_first[b + 1] - s->band_first[b]) * (uint32_t)(RTC_TILE_W * RTC_TILE_H);
+        if (int rc = run_job(s, band, s->band_render_stream, nullptr, 0)) return rc;
+        HIP_TRY(hipEventRecord(s->band_events[b], s->band_render_stream));
+        HIP_TRY(hipStreamWaitEvent(s->band_copy_stream, s->band_events[b], 0));
+        for (; k < slices_end[b]; ++k) {
+            HIP_TRY(hipMemcpyAsync((char*)s->h_staging + slices[k].begin, d_src + slices[k].begin, slices[k].len,
+                                   hipMemcpyDeviceToHost, s->band_copy_stream));
+            HIP_TRY(hipEventRecord(s->slice_events[k], s->band_copy_stream));
+        }
+    }
+    const int rc = move_slices_to_caller(s, out_host, slices);
+    HIP_TRY(hipStreamSynchronize(s->band_render_stream));
+    HIP_TRY(hipStreamSynchronize(s->band_copy_stream));
+    return rc;
+}
+
 int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, double* out_rgb, RtcStats* stats) {
     if (!scene) return fail(RTC_ERR_INVALID_ARGUMENT, "scene is NULL");
     if (!out_rgb) return fail(RTC_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
@@ -1848,6 +1986,11 @@ int rtc_render(RtcScene* scene, const RtcCameraDesc* camera, int32_t depth, doub
         scene->canvas_bytes = bytes;
     }
     double* d_out = scene->d_canvas;
+    // large canvases, when nobody asks for the counters of ONE launch: bands, rendering and copying at the same time
+    static const bool bands_off = std::getenv("RTC_NO_BANDS") != nullptr;  // developer switch for timing
+    const uint32_t tile_rows = ((uint32_t)camera->vsize + RTC_TILE_H - 1) / RTC_TILE_H;
+    if (!stats && !bands_off && bytes >= (64u << 20) && tile_rows >= 4 * kBands && have_staging(scene, bytes))
+        return render_to_host_in_bands(scene, camera, depth, d_out, out_rgb);
     int rc = rtc_render_device(scene, camera, depth, 0, 1, d_out, nullptr, stats);
     if (rc == RTC_OK) rc = copy_canvas_to_host(scene, d_out, out_rgb, bytes);
     return rc;

@@ -1834,7 +1834,6 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     constexpr bool STREAM = TABLES == 0;
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS> hot;
-    const int tid = (int)threadIdx.x;
     if constexpr (LDS) {
         const int n = wc.n;
         for (int k = (int)threadIdx.x; k < n * 12; k += kBlock) hot.mat[k / 12][k % 12] = g_inv[k];

@@ -812,6 +812,46 @@ def test_two_handles_render_concurrently_on_two_streams():
                 assert_identical(t.cpu().numpy().reshape(cd.vsize, cd.hsize, 3), want, f"handle {h}, frame {k + 1}")
 
 
+def test_host_canvas_of_a_large_frame_rendered_in_bands():
+    """rtc_render of a canvas of 64 MB and more renders the frame in bands of tile rows, one launch each, and copies a
+    band to the host while the next one is rendered.  Only the schedule differs: the caller's canvas is the one
+    rtc_render_device leaves in device memory (itself checked against the oracle on sampled rows), for a ragged size,
+    a repeated and a changed camera, with block stores, and with the weighted integrator at its tolerance; a call that
+    asks for statistics takes the single launch and gives the same canvas."""
+    import torch
+
+    w, cam = scenes.draw_world_scene(3833, 2161)
+    cd = cam.desc()
+    rows = (5, 2161, 211)
+    want_rows = O.render(w, cam, 5, O.STREAMING, rows=rows)
+    with scene_of(w) as sc:
+        dev = torch.empty(cd.hsize * cd.vsize * 3, dtype=torch.float64, device="cuda")
+        sc.render_device(cd, 5, dev.data_ptr())
+        torch.cuda.synchronize()
+        want = dev.cpu().numpy().reshape(cd.vsize, cd.hsize, 3)
+        assert_identical(want[rows[0]::rows[2]], want_rows[rows[0]::rows[2]], "device canvas against the oracle's rows")
+        for k in range(2):
+            assert np.array_equal(np.asarray(sc.render(cd, 5)).reshape(want.shape), want), f"bands, frame {k + 1}"
+        st = D.RtcStats()
+        assert np.array_equal(np.asarray(sc.render(cd, 5, st)).reshape(want.shape), want), "single launch with statistics"
+        assert st.radiance_rays > cd.hsize * cd.vsize
+        # (the 8-bit image of the same handle, a single launch: ppm.zig:6-9)
+        assert np.array_equal(sc.render_u8(cd, 5), byte_color_values(want)), "8-bit image"
+        sc.set_canvas_store(D.RTC_CANVAS_STORE_BLOCKS)
+        assert np.array_equal(np.asarray(sc.render(cd, 5)).reshape(want.shape), want), "bands with block stores"
+        sc.set_canvas_store(D.RTC_CANVAS_STORE_PIXELS)
+        _, other = scenes.draw_world_scene(4000, 1500)
+        od = other.desc()
+        sc.render_device(od, 5, dev.data_ptr())
+        torch.cuda.synchronize()
+        want_other = dev[: od.hsize * od.vsize * 3].cpu().numpy()
+        assert np.array_equal(np.asarray(sc.render(od, 5)).reshape(-1), want_other), "another camera"
+        assert np.array_equal(np.asarray(sc.render(cd, 5)).reshape(want.shape), want), "back to the first camera"
+        sc.set_integrator(D.RTC_INTEGRATOR_WEIGHTED)
+        got = np.asarray(sc.render(cd, 5)).reshape(want.shape)
+        assert float(np.abs(got - want).max()) <= 1e-9, "weighted integrator in bands"
+
+
 def test_one_scene_many_cameras():
     """The queue order is planned per camera from where the transparent shapes project to and is
     cached in the scene handle: different cameras on one handle (glass in view, off to a side,
