@@ -1,6 +1,7 @@
 """Developer tool: randomised parity campaign.  Seeded random worlds (0-40 spheres, 0-4 planes,
 glass and mirrors, patterns), random canvas sizes, depths 0-7, list walk and hierarchy, whole
-canvas and interleaved partitions, each compared value for value with the CPU oracle (the
+canvas (also with a repeated camera, whose queue is dealt in strips) and interleaved partitions, each compared value
+for value with the CPU oracle (the
 attenuation-weighted integrator: to 1e-9)
 (streaming integrator; every 10th world also with the literal one).  Runs until the time budget
 is spent and prints the seeds that differ.
@@ -41,6 +42,9 @@ while time.time() < t_end:
             gpu = sc.render(cd, depth, st)
             rays += st.radiance_rays
             assert np.array_equal(gpu, cpu, equal_nan=True), "list walk"
+            # the same camera again: from its second frame on the queue is dealt in strips
+            for k in range(2):
+                assert np.array_equal(sc.render(cd, depth), cpu, equal_nan=True), f"repeated camera, frame {k + 2}"
             if n_s > 0:
                 sc.set_acceleration(D.RTC_ACCEL_BVH)
                 assert np.array_equal(sc.render(cd, depth), cpu, equal_nan=True), "hierarchy"
