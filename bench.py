@@ -312,6 +312,9 @@ def main():
                     help="rtc_scene_set_canvas_store for the headline leg: every finished pixel stored at once (default) "
                     "or whole 8x8 blocks (meant for a canvas in a peer GPU's memory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-leg", action="store_true",
+                    help="leave out the stream-of-frames leg (its launches overlap each other, which would blur a "
+                    "profiler's per-launch average of the render kernel)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     # developer switches to rehearse the N > 1 path on a box with one GPU: every rank uses GPU 0
     # and the gather goes through host memory over gloo (never used for reported numbers)
@@ -870,7 +873,7 @@ def main():
         if world_size == 1 and not args.accel and not weighted:
             out["config"]["weighted_integrator"] = weighted_integrator_leg(torch, native, D, scene, cam, args, local, stream,
                                                                            total["radiance_rays"])
-        if world_size == 1 and not args.accel and not weighted:
+        if world_size == 1 and not args.accel and not weighted and not args.no_stream_leg:
             out["config"]["stream_of_frames"] = frames_in_flight_leg(torch, native, D, world, cam, args, local,
                                                                      total["radiance_rays"])
         if world_size == 1 and args.multi_ranks > 0:

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 pass() {
   name=$1; shift
-  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $name -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1
+  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $name -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stream-leg $BENCH_ARGS > $OUT/$name.log 2>&1
   rc=$?
   echo "pass $name rc=$rc"
   return $rc

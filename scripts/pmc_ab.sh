@@ -23,7 +23,7 @@ for spec in "$@"; do
   mkdir -p $d
   pass() {
     p=$1; shift
-    timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $d -o $p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $WL > $d/$p.log 2>&1 || { echo "pass $p of $name failed"; tail -5 $d/$p.log; exit 1; }
+    timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $d -o $p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stream-leg --workload $WL > $d/$p.log 2>&1 || { echo "pass $p of $name failed"; tail -5 $d/$p.log; exit 1; }
   }
   pass A SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE
   pass B SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAVES

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 export RTC_HIP_LIB=$R/$LIB
 pass() {
   p=$1; shift
-  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $WL > $OUT/$p.log 2>&1 || { echo "pass $p failed"; tail -5 $OUT/$p.log; exit 1; }
+  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stream-leg --workload $WL > $OUT/$p.log 2>&1 || { echo "pass $p failed"; tail -5 $OUT/$p.log; exit 1; }
 }
 pass I SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES
 pass D SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQ_INSTS_SMEM SQC_TC_STALL

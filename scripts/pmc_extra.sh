@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 export RTC_HIP_LIB=$R/$LIB
 pass() {
   p=$1; shift
-  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $WL > $OUT/$p.log 2>&1 || { echo "pass $p failed"; tail -5 $OUT/$p.log; exit 1; }
+  timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stream-leg --workload $WL > $OUT/$p.log 2>&1 || { echo "pass $p failed"; tail -5 $OUT/$p.log; exit 1; }
 }
 pass L SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT
 pass M SQ_INSTS_VALU_CVT SQ_INSTS_VALU_IOPS SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_IFETCH_LEVEL SQ_INSTS_SMEM

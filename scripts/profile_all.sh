@@ -12,7 +12,7 @@ for W in "$@"; do
   STEPS=20; [ "$W" = c4 ] && STEPS=3
   P=$R/gpurun_out/prof_${TAG}_$W
   mkdir -p $P
-  ( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $P -o $W -- python3 $R/bench.py --workload $W --steps $STEPS --warmup 3 --no-cpu-baseline > $P/bench.log 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $P -o $W -- python3 $R/bench.py --workload $W --steps $STEPS --warmup 3 --no-cpu-baseline --no-stream-leg > $P/bench.log 2>&1 )
   rc=$?; echo "kernel-trace $W rc=$rc"; [ $rc -ne 0 ] && exit 1
   DB=$(ls $P/*_results.db $P/*/*_results.db 2>/dev/null | head -1)
   python3 $R/scripts/rocprof_summary.py "$DB" | sed "s#$R/##" > $DST/${PREFIX}_${W}_kernel_stats_$TAG.txt
