@@ -852,6 +852,27 @@ def test_host_canvas_of_a_large_frame_rendered_in_bands():
         assert float(np.abs(got - want).max()) <= 1e-9, "weighted integrator in bands"
 
 
+@pytest.mark.parametrize("n_spheres", [13, 14, 29])
+def test_worlds_on_either_side_of_the_small_table_limit(n_spheres):
+    """Worlds of spheres stretched along the axes and planes only take the kernels without the general kinds; the
+    post-order ones keep per-hit tables for 16 shapes (the LDS beside them holds the parked rays of the chunk in hand)
+    and larger worlds of this sort use the general kernels with tables for 32: 16, 17 and 32 shapes, both integrators,
+    first frame and repeated camera."""
+    w, c = random_world(4242 + n_spheres, n_spheres=n_spheres, n_planes=3, glass=True, axis_only=True)
+    assert len(w.objects) == n_spheres + 3
+    cam = Camera(150, 70, c.field_of_view)
+    cam.transform = c.transform
+    want = O.render(w, cam, 5, O.STREAMING)
+    with scene_of(w) as sc:
+        for k in range(3):
+            assert_identical(sc.render(cam.desc(), 5), want, f"{len(w.objects)} shapes, frame {k + 1}")
+        sc.set_integrator(D.RTC_INTEGRATOR_WEIGHTED)
+        got = sc.render(cam.desc(), 5)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin)
+        assert float(np.abs(got[fin] - want[fin]).max(initial=0.0)) <= 1e-9 * max(1.0, float(np.abs(want[fin]).max(initial=0.0)))
+
+
 def test_one_scene_many_cameras():
     """The queue order is planned per camera from where the transparent shapes project to and is
     cached in the scene handle: different cameras on one handle (glass in view, off to a side,
