@@ -1526,6 +1526,21 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     do {               \
     } while (0)
 #endif
+#ifdef RTC_LANE_MAP
+    // developer build (with RTC_PROBE): per region of the loop, how many lanes enter it (lm) and how many times a wave
+    // does (lw: counted by the first active lane) - the regions' lane utilisation
+    uint32_t lm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lw[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define RTC_LANE(k)                                                                                                         \
+    do {                                                                                                                    \
+        ++lm[k];                                                                                                            \
+        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u) \
+            ++lw[k];                                                                                                        \
+    } while (0)
+#else
+#define RTC_LANE(k) \
+    do {            \
+    } while (0)
+#endif
     for (;;) {
         // ---- hand new pixels to idle lanes ----------------------------------------------
         // The wave draws chunks of kChunk consecutive queue positions (one 8x8 pixel block)
@@ -1635,7 +1650,9 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
 #ifdef RTC_PROBE
         ++pcv[pc_iters];
 #endif
+        if (mode != kIdle) RTC_LANE(0);
         if (mode == kRun && !(aux & kAuxWaiting) && !have_ret) {
+            RTC_LANE(1);
             // ---- one tree node: calc.worldColorAt (calc.zig:641-652) ---------------------
             if (STATS) ++n_radiance;
 #ifdef RTC_COSTMAP
@@ -1648,8 +1665,10 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
 
             have_ret = true;
             if (hit.idx >= 0) {
+                RTC_LANE(2);
 #include "rtc_node.inc"
                 if (has_reflect || has_refract) {
+                    RTC_LANE(8);
                     // a frame holds only what its unwinding will read: most frames (a reflective,
                     // opaque surface) are the colour so far and the meta word
                     set_frame_acc(sp, surface);
@@ -1687,6 +1706,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
         RTC_STAMP(pc_push);
         // ---- unwind finished subtrees in the reference's post-order -----------------------
         if (have_ret) {
+            RTC_LANE(9);
             bool settled = false;  // the lane descended into a child or waits for a helper
             // One pass over the levels from the deepest to the root instead of a loop over the
             // lane's own frames: a lane pops level L when that is its top frame, so every lane is
@@ -1695,6 +1715,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
 #pragma unroll
             for (int L = MAXD - 1; L >= 0; --L) {
                 if (!settled && sp == L + 1) {
+                    RTC_LANE(10 + (L < 4 ? L : 4));
                     const int flags = frame_meta(L);
                     const V3 acc0 = frame_acc(L);
                     // The returned child is the reflected one (color.scale(reflective), then
@@ -1734,6 +1755,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
                     mode = kHelperDone;
                 } else {
                     // canvas.set (canvas.zig:24-28)
+                    RTC_LANE(15);
 #ifdef RTC_COSTMAP
                     ret = {(double)cost_nodes, 0.0, 0.0};  // developer build: nodes traced per pixel instead of the colour
 #endif
@@ -1799,6 +1821,19 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
             for (int q = 0; q < 16; ++q) pc[q] = pcv[q];
         }
     }
+#ifdef RTC_LANE_MAP
+    for (int q = 0; q < 16; ++q) {
+        unsigned long long v = (unsigned long long)lm[q] | ((unsigned long long)lw[q] << 32);
+        unsigned long long lo = v & 0xffffffffull, hi = v >> 32;
+        for (int off = 32; off > 0; off >>= 1) lo += __shfl_down(lo, off), hi += __shfl_down(hi, off);
+        const unsigned wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (lane == 0 && wid < 8192) {
+            unsigned long long* pr = (unsigned long long*)((char*)g_counter + kProbeOffsetBytes);
+            // (iterations stay in slot 15's high half: lw[0] is the wave's iteration count as well)
+            pr[3 * 8192 + wid * 16 + q] = (lo & 0xffffffffull) | (hi << 32);
+        }
+    }
+#endif
 #endif
     if (STATS) {
         // one atomic per counter per wave
@@ -1815,6 +1850,10 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
 #undef RTC_STAMP
 #define RTC_STAMP(acc) \
     do {               \
+    } while (0)
+#undef RTC_LANE
+#define RTC_LANE(k) \
+    do {            \
     } while (0)
 
 // The attenuation-weighted integrator (rtc_scene_set_integrator: RTC_INTEGRATOR_WEIGHTED).
