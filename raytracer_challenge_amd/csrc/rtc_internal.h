@@ -22,6 +22,9 @@ constexpr int kMaxDepthLarge = 16;
 #define RTC_QUEUES 16
 #endif
 constexpr int kQueues = RTC_QUEUES;
+#ifndef RTC_DRAW_THRESHOLD
+#define RTC_DRAW_THRESHOLD 40  // idle lanes a wave waits for before it draws its next chunk (rtc_refill.inc)
+#endif
 constexpr int kQueueStrideWords = 32;  // uint32 words between queue heads
 constexpr int kStatsOffsetBytes = kQueues * kQueueStrideWords * 4;
 constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 128;

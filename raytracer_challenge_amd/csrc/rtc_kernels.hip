@@ -1394,6 +1394,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     constexpr bool ACCEL = TABLES == 2;
     constexpr bool STREAM = TABLES == 0;  // large world, list walk: the spheres' bounds are streamed from their side tables
     constexpr bool PARK = SLIM && !FROM_RAYS;
+    constexpr int kDrawThreshold = STREAM ? 0 : RTC_DRAW_THRESHOLD;  // (rtc_refill.inc)
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS, SLIM ? kSlimShapes : kLdsShapes> hot;
     __shared__ FrameSlots frames;
@@ -1887,6 +1888,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     constexpr bool SLIM = TABLES == 3;  // (see launch_variant)
     constexpr bool ACCEL = TABLES == 2;
     constexpr bool STREAM = TABLES == 0;
+    constexpr int kDrawThreshold = STREAM ? 0 : RTC_DRAW_THRESHOLD;  // (rtc_refill.inc)
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS, kLdsShapes> hot;
     if constexpr (LDS) {
