@@ -1300,7 +1300,11 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
 constexpr int kLdsShapes = kLdsShapeLimit;
 // (the kernels of launch_variant's TABLES == 3 keep tables for kSlimShapes shapes and use the room for the parked
 // rays of the chunk in hand, see ParkedRays)
+#ifdef RTC_NO_PARK  // developer switch, for comparison: no parked rays, tables for kLdsShapes shapes
+constexpr int kSlimShapes = kLdsShapes;
+#else
 constexpr int kSlimShapes = kLdsShapes < 16 ? kLdsShapes : 16;
+#endif
 template <bool ON, int N>
 struct HotTables {};
 template <int N>
@@ -1393,7 +1397,11 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     constexpr bool SLIM = TABLES == 3;  // (see launch_variant)
     constexpr bool ACCEL = TABLES == 2;
     constexpr bool STREAM = TABLES == 0;  // large world, list walk: the spheres' bounds are streamed from their side tables
+#ifdef RTC_NO_PARK
+    constexpr bool PARK = SLIM && !FROM_RAYS && MAXD < 0;  // (never; the expression stays dependent on the template arguments)
+#else
     constexpr bool PARK = SLIM && !FROM_RAYS;
+#endif
     constexpr int kDrawThreshold = STREAM ? 0 : RTC_DRAW_THRESHOLD;  // (rtc_refill.inc)
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS, SLIM ? kSlimShapes : kLdsShapes> hot;
