@@ -25,6 +25,9 @@ constexpr int kQueues = RTC_QUEUES;
 #ifndef RTC_DRAW_THRESHOLD
 #define RTC_DRAW_THRESHOLD 40  // idle lanes a wave waits for before it draws its next chunk (rtc_refill.inc)
 #endif
+#ifndef RTC_DEAL_THRESHOLD
+#define RTC_DEAL_THRESHOLD 24  // ... and before it deals what a draw has left over (or as many as are left)
+#endif
 constexpr int kQueueStrideWords = 32;  // uint32 words between queue heads
 constexpr int kStatsOffsetBytes = kQueues * kQueueStrideWords * 4;
 constexpr int kProbeOffsetBytes = kStatsOffsetBytes + 128;
