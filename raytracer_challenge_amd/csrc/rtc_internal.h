@@ -23,10 +23,7 @@ constexpr int kMaxDepthLarge = 16;
 #endif
 constexpr int kQueues = RTC_QUEUES;
 #ifndef RTC_DRAW_THRESHOLD
-#define RTC_DRAW_THRESHOLD 40  // idle lanes a wave waits for before it draws its next chunk (rtc_refill.inc)
-#endif
-#ifndef RTC_DEAL_THRESHOLD
-#define RTC_DEAL_THRESHOLD 24  // ... and before it deals what a draw has left over (or as many as are left)
+#define RTC_DRAW_THRESHOLD 64  // idle lanes a wave waits for before it draws its next chunk (rtc_refill.inc)
 #endif
 constexpr int kQueueStrideWords = 32;  // uint32 words between queue heads
 constexpr int kStatsOffsetBytes = kQueues * kQueueStrideWords * 4;

@@ -1298,24 +1298,17 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int n) {
 // LDS access instead of a chain of dependent trips to the L2, which four waves per SIMD
 // cannot hide.  Larger worlds spend their time in the sweeps and gather from global memory.
 constexpr int kLdsShapes = kLdsShapeLimit;
-// (the kernels of launch_variant's TABLES == 3 keep tables for kSlimShapes shapes and use the room for the parked
-// rays of the chunk in hand, see ParkedRays)
-#ifdef RTC_NO_PARK  // developer switch, for comparison: no parked rays, tables for kLdsShapes shapes
-constexpr int kSlimShapes = kLdsShapes;
-#else
-constexpr int kSlimShapes = kLdsShapes < 16 ? kLdsShapes : 16;
-#endif
-template <bool ON, int N>
+template <bool ON>
 struct HotTables {};
-template <int N>
-struct HotTables<true, N> {
-    double mat[N][12];
-    DevShade shade[N];
+template <>
+struct HotTables<true> {
+    double mat[kLdsShapes][12];
+    DevShade shade[kLdsShapes];
 #ifdef RTC_LDS_SWEEP
     // developer switch, for comparison (build with -DRTC_LDS_SHAPES=16 so that the workgroup's LDS still allows four per
     // CU): the sweep table in LDS too, read with wave-uniform LDS addresses - a broadcast into VECTOR registers - instead
     // of scalar loads into scalar registers
-    double tab[(N + 2) * kRecDoubles];
+    double tab[(kLdsShapes + 2) * kRecDoubles];
 #endif
 };
 static_assert(sizeof(DevShade) % 8 == 0, "DevShade is copied as 8-byte words");
@@ -1355,15 +1348,6 @@ __device__ __forceinline__ WorldArg world_argument() {
 // synchronisation: it parks finished colours in a staging area of its own (global memory; kFlushSlots blocks in
 // flight per wave, a block that finds no free slot falls back to per-pixel stores) and, when the last pixel of a
 // block is done, copies the block out with all 64 lanes in one go: eight runs of 192 contiguous bytes.
-// The primary rays of the chunk a wave has drawn, one per queue position (rtc_refill.inc): direction and output slot
-// (0xffffffff: no pixel at this position); the origin is the camera's for all of them.
-template <bool ON>
-struct ParkedRays {};
-template <>
-struct ParkedRays<true> {
-    double rd[3][kBlock];
-    uint32_t out[kBlock];
-};
 constexpr uint32_t kOutStaged = 0x80000000u;  // out_pixel holds (slot << 6 | position in the block), not a canvas index
 template <bool ON>
 struct FlushTable {};
@@ -1397,16 +1381,10 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     constexpr bool SLIM = TABLES == 3;  // (see launch_variant)
     constexpr bool ACCEL = TABLES == 2;
     constexpr bool STREAM = TABLES == 0;  // large world, list walk: the spheres' bounds are streamed from their side tables
-#ifdef RTC_NO_PARK
-    constexpr bool PARK = SLIM && !FROM_RAYS && MAXD < 0;  // (never; the expression stays dependent on the template arguments)
-#else
-    constexpr bool PARK = SLIM && !FROM_RAYS;
-#endif
     constexpr int kDrawThreshold = STREAM ? 0 : RTC_DRAW_THRESHOLD;  // (rtc_refill.inc)
     __shared__ ContainerSlots containers;
-    __shared__ HotTables<LDS, SLIM ? kSlimShapes : kLdsShapes> hot;
+    __shared__ HotTables<LDS> hot;
     __shared__ FrameSlots frames;
-    __shared__ ParkedRays<PARK> park;
     const int tid = (int)threadIdx.x;
     if constexpr (LDS) {
         const int n = wc.n;
@@ -1569,9 +1547,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
         sp = 0;                           \
     } while (0)
 #define RTC_REFILL_BLOCK_SLOTS
-#define RTC_REFILL_PARK
 #include "rtc_refill.inc"
-#undef RTC_REFILL_PARK
 #undef RTC_REFILL_BLOCK_SLOTS
 #undef RTC_START_TASK
         const bool drained = exhausted && loc_next >= loc_end;  // wave-uniform: no pixel left to start
@@ -1898,7 +1874,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     constexpr bool STREAM = TABLES == 0;
     constexpr int kDrawThreshold = STREAM ? 0 : RTC_DRAW_THRESHOLD;  // (rtc_refill.inc)
     __shared__ ContainerSlots containers;
-    __shared__ HotTables<LDS, kLdsShapes> hot;
+    __shared__ HotTables<LDS> hot;
     if constexpr (LDS) {
         const int n = wc.n;
         for (int k = (int)threadIdx.x; k < n * 12; k += kBlock) hot.mat[k / 12][k % 12] = g_inv[k];
@@ -2223,7 +2199,7 @@ hipError_t launch_variant(const DevWorld& world, const DevJob& job, hipStream_t 
         // kernels without the loops and the normal arithmetic of the general kinds: TABLES == 3.  Only the frame
         // kernels (no statistics, camera rays) exist in that form.
         if constexpr (!STATS && !FROM_RAYS) {
-            if (world.group[1] == world.group[2] && world.group[4] == world.group[5] && (world.n <= kSlimShapes || job.weighted))
+            if (world.group[1] == world.group[2] && world.group[4] == world.group[5])
                 return launch_tables<MAXD, STATS, FROM_RAYS, 3>(world, job, stream);
         }
         return launch_tables<MAXD, STATS, FROM_RAYS, 1>(world, job, stream);
