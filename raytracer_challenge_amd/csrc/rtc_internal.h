@@ -192,7 +192,9 @@ struct DevJob {
     // block stores (rtc_scene_set_canvas_store): the waves' staging area, kFlushSlots x 64 pixels x 3 doubles for each
     // of the first flush_waves waves of the grid, or nullptr = every pixel is stored when it is finished
     double* flush_stage;
-    uint32_t flush_waves, flush_pad;
+    uint32_t flush_waves;
+    // idle lanes a wave waits for before it draws its next chunk (rtc_refill.inc; kernels of small worlds only)
+    uint32_t draw_threshold;
     uint32_t* counter;  // control block: the work-queue heads first, zeroed before the launch
     uint64_t* stats;    // 9 counters (radiance, shadow, sphere hits, plane hits, shaded, sphere skips, plane skips, cube hits, prefilter skips) or nullptr
 };

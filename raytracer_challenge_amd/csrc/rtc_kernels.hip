@@ -1381,7 +1381,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     constexpr bool SLIM = TABLES == 3;  // (see launch_variant)
     constexpr bool ACCEL = TABLES == 2;
     constexpr bool STREAM = TABLES == 0;  // large world, list walk: the spheres' bounds are streamed from their side tables
-    constexpr int kDrawThreshold = STREAM ? 0 : RTC_DRAW_THRESHOLD;  // (rtc_refill.inc)
+    constexpr int kDrawThreshold = STREAM ? 0 : 1;  // whether job.draw_threshold applies (rtc_refill.inc)
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS> hot;
     __shared__ FrameSlots frames;
@@ -1872,7 +1872,7 @@ __global__ __launch_bounds__(kBlock, TABLES == 0 ? RTC_WAVES_PER_EU_LARGE : RTC_
     constexpr bool SLIM = TABLES == 3;  // (see launch_variant)
     constexpr bool ACCEL = TABLES == 2;
     constexpr bool STREAM = TABLES == 0;
-    constexpr int kDrawThreshold = STREAM ? 0 : RTC_DRAW_THRESHOLD;  // (rtc_refill.inc)
+    constexpr int kDrawThreshold = STREAM ? 0 : 1;  // whether job.draw_threshold applies (rtc_refill.inc)
     __shared__ ContainerSlots containers;
     __shared__ HotTables<LDS> hot;
     if constexpr (LDS) {
