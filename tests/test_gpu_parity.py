@@ -853,11 +853,9 @@ def test_host_canvas_of_a_large_frame_rendered_in_bands():
 
 
 @pytest.mark.parametrize("n_spheres", [13, 14, 29])
-def test_worlds_on_either_side_of_the_small_table_limit(n_spheres):
-    """Worlds of spheres stretched along the axes and planes only take the kernels without the general kinds; the
-    post-order ones keep per-hit tables for 16 shapes (the LDS beside them holds the parked rays of the chunk in hand)
-    and larger worlds of this sort use the general kernels with tables for 32: 16, 17 and 32 shapes, both integrators,
-    first frame and repeated camera."""
+def test_worlds_up_to_the_small_table_limit(n_spheres):
+    """Worlds of spheres stretched along the axes and planes only take the kernels without the general kinds, up to the
+    32 shapes their on-chip tables hold: 16, 17 and 32 shapes, both integrators, first frame and repeated camera."""
     w, c = random_world(4242 + n_spheres, n_spheres=n_spheres, n_planes=3, glass=True, axis_only=True)
     assert len(w.objects) == n_spheres + 3
     cam = Camera(150, 70, c.field_of_view)

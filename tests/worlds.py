@@ -9,8 +9,8 @@ from raytracer_challenge_amd import (Camera, Color, Mat4, Material, Pattern, Poi
 
 def random_world(seed, n_spheres=6, n_planes=2, glass=True, n_cubes=0, axis_only=False):
     """axis_only: the spheres are ellipsoids along the axes (scale and translation only: diagonal inverses) and every
-    shininess is an integer, as in the reference's own scenes; such worlds of at most 16 shapes (32 with the weighted
-    integrator) are rendered by the kernels without the general kinds."""
+    shininess is an integer, as in the reference's own scenes; such worlds of at most 32 shapes are rendered by the
+    kernels without the general kinds."""
     rng = np.random.default_rng(seed)
     u = lambda lo, hi: float(rng.uniform(lo, hi))
     w = World()
