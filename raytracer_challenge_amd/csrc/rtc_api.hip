@@ -653,16 +653,16 @@ int compute_tile_order(const RtcScene* s, const RtcCameraDesc* cam, const rtc::D
     for (uint32_t i = 0; i < tiles_y; ++i) start[i + 1] += start[i];
     order.resize(local_tiles);
     for (uint64_t k = 0; k < local_tiles; ++k) order[start[rank_of_row[(k * ranks + rank) / tiles_x]]++] = (uint32_t)k;
-    // A block of 64 such pixels keeps its wave for some 60 node iterations, about 0.4 ms: on a
-    // share of the frame that the whole GPU finishes in little more than that, every one of them
-    // must be some wave's first block, so the tiles a transparent shape can show go to the front
-    // of the queue (in the row order above).  On larger shares the rows stay whole (measured at
-    // 7680x4320: 10.08 against 10.31 ms).
+    // A block of 64 such pixels keeps its wave for some 60 node iterations, about 0.4 ms: every one of them should be
+    // some wave's first block, so the tiles a transparent shape can show go to the front of the queue (in the row order
+    // above): the 4K reference frame 1.89 -> 1.84 ms on the first frame of a camera (the strip table of a camera that
+    // repeats, which does the same at the granularity of blocks, gives 1.83 ms).  On large frames the rows stay whole
+    // (7680x4320: no difference now, 10.08 against 10.31 ms when the pixels of a wave were dealt lane by lane).
     int dev = 0, cus = 0;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const uint64_t resident_waves = (uint64_t)cus * 16;
-    if (local_tiles * (RTC_TILE_W * RTC_TILE_H / 64) <= 10 * resident_waves) {
+    if (local_tiles * (RTC_TILE_W * RTC_TILE_H / 64) <= 48 * resident_waves) {
         auto marked = [&](uint32_t k) {
             const uint32_t tx = (uint32_t)(((uint64_t)k * ranks + rank) % tiles_x), ty = (uint32_t)(((uint64_t)k * ranks + rank) / tiles_x);
             for (const TileBox& b : boxes)
