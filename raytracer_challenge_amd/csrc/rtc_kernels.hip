@@ -514,7 +514,9 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
             const double guard = rec.side_guard * side_scale;
             if (loy * rec.light_side > guard && rec.light_height > guard) {
                 if (!STATS) return;
+#ifndef RTC_ITEM_STATS
                 ++ctr.plane_skips;
+#endif
             }
         }
         if (KIND == kPlaneAxis) {
@@ -523,7 +525,9 @@ __device__ __forceinline__ void sweep_shape(const ShapeRec& rec, int pos, const 
             ldy = (m[4] * d.x + m[5] * d.y) + m[6] * d.z;
         }
         const bool hits = !(fabs(ldy) < kF64Eps);
+#ifndef RTC_ITEM_STATS
         if (STATS && hits) ++ctr.plane_hits;
+#endif
         // A radiance sweep needs t of nearly every plane anyway (a plane behind the origin is a
         // container, and some lane of the wave usually has it behind), so only the shadow sweep
         // pays for deciding whether the division can be left out.
@@ -971,6 +975,13 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
 #endif
                     const int i = cands_first + (__ffs((int)cands) - 1);
                     cands &= cands - 1u;
+#ifdef RTC_ITEM_STATS
+                    if (STATS) {
+                        ++ctr.sphere_prefilter_skips;  // lanes in a trip of sphere tests ...
+                        if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u)
+                            ++ctr.plane_skips;  // ... and such trips
+                    }
+#endif
                     // The double-precision bounding test dismisses one in sixty of the spheres that get here (the
                     // packed test is nearly as sharp) and costs a round trip to memory ahead of the record's: only
                     // the statistics build runs it, to count as the other sweeps do.  The full test finds the same
@@ -1030,10 +1041,14 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                 const float* __restrict__ src = pairs + ((size_t)table + (size_t)((uint32_t)first >> unit_log2) * 4);
                 const uint32_t real = real_bits(first, unit_log2);
                 const uint32_t open = eight(src, level == 0 ? r32.a : a_blocks, level == 0 ? r32.b : b_blocks) & real;
+#ifndef RTC_ITEM_STATS
                 if (STATS) count_dismissed(real & ~open, first, unit_log2);
+#endif
 #ifdef RTC_ITEM_STATS
                 if (STATS) {
                     ++ctr.cube_hits;                   // items of the work loop
+                    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(1) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(1), 0u)) == 0u)
+                        ++ctr.plane_hits;              // trips of the loop that work on items (one count per wave)
                     if (open == 0u) ++ctr.sphere_hits;  // ... none of whose eight entries survived
                     // would the item's OWN bound, tested again with the stretch as it is now, have dismissed it?
                     const uint32_t own_table = level == 0 ? block_pairs_offset : (level == 1 ? super_pairs_offset : group_pairs_offset);
@@ -1046,7 +1061,6 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
                     bool d0, d1;
                     pair_clear<SHADOW, true>(one, rr, d0, d1);
                     if (d0) ++ctr.sphere_skips;
-                    if (d0 && open != 0u) ++ctr.plane_hits;  // (must never happen: the parent's test implies the children's)
                 }
 #endif
                 cands = level == 0 ? open : 0u;
@@ -1075,7 +1089,9 @@ __device__ __forceinline__ void sweep_spheres_lanes(const float* __restrict__ pa
         const uint32_t real = real_bits(i, top_log2);  // wave-uniform
         const uint32_t need = ((b0 ? 0u : 1u) | (b1 ? 0u : 2u) | (b2 ? 0u : 4u) | (b3 ? 0u : 8u) | (b4 ? 0u : 16u) |
                                (b5 ? 0u : 32u) | (b6 ? 0u : 64u) | (b7 ? 0u : 128u)) & real;
+#ifndef RTC_ITEM_STATS
         if (STATS) count_dismissed(real & ~need, i, top_log2);
+#endif
         const int slot = trip & 7;
         pending |= (unsigned long long)need << (slot * 8);
         if (slot == 7 || i + per_trip >= end) {
